@@ -1,0 +1,242 @@
+"""ctypes binding of libalac_hip.so (the C-ABI declared in include/alac_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call below hands raw device
+pointers to the HIP library.  There is no CPU fallback: if the library or a GPU is missing the
+import of the library / creation of a context raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libalac_hip.so")
+SYNTH_PATH = os.path.join(_HERE, "libalac_synth.so")
+
+STATE_INT16 = 64
+BPS = {16: 2, 20: 3, 24: 3, 32: 4}
+
+
+class Format(C.Structure):
+    _fields_ = [("frame_size", C.c_uint32), ("bit_depth", C.c_uint32), ("num_channels", C.c_uint32),
+                ("sample_rate", C.c_uint32)]
+
+    @property
+    def bytes_per_frame(self):
+        return self.num_channels * BPS[self.bit_depth]
+
+    @property
+    def packet_bytes(self):
+        return self.frame_size * self.bytes_per_frame
+
+
+def make_format(frame_size=4096, bit_depth=16, num_channels=2, sample_rate=44100):
+    return Format(frame_size, bit_depth, num_channels, sample_rate)
+
+
+_vp, _u32, _i32, _u64 = C.c_void_p, C.c_uint32, C.c_int32, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/alac_hip.h one to one
+SIGNATURES = {
+    "alac_hip_device_count": (_i32, []),
+    "alac_hip_create": (_i32, [C.POINTER(_vp), _i32, _vp]),
+    "alac_hip_destroy": (None, [_vp]),
+    "alac_hip_synchronize": (_i32, [_vp]),
+    "alac_hip_last_error": (C.c_char_p, [_vp]),
+    "alac_hip_stream": (_vp, [_vp]),
+    "alac_hip_encode_workspace_bytes": (_u64, [C.POINTER(Format), _u32, _u32]),
+    "alac_hip_encode_max_output_bytes": (_u64, [C.POINTER(Format), _u32]),
+    "alac_hip_encode": (_i32, [_vp, C.POINTER(Format), _vp, _vp, _u32, _vp, _u32, _vp, _i32, _vp, _u64,
+                               _vp, _u64, _vp, _vp]),
+    "alac_hip_magic_cookie": (_u32, [C.POINTER(Format), _u32, _u32, _vp]),
+    "alac_hip_decode_workspace_bytes": (_u64, [C.POINTER(Format), _u32]),
+    "alac_hip_decode": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "alac_hip_format_from_cookie": (_i32, [_vp, _u32, C.POINTER(Format)]),
+    "alac_hip_pc_block": (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _i32, _u32, _u32]),
+    "alac_hip_unpc_block": (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _i32, _u32, _u32]),
+    "alac_hip_dyn_comp": (_i32, [_vp, _u32, _u32, _u32, _vp, _u32, _u32, _i32, _i32, _vp, _u32, _vp]),
+    "alac_hip_dyn_decomp": (_i32, [_vp, _u32, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _i32, _i32, _vp, _vp]),
+    "alac_hip_encode_host": (_i32, [_vp, C.POINTER(Format), _vp, _u64, _u32, _vp, _i32, _vp, _u64, _vp,
+                                    C.POINTER(_u64)]),
+    "alac_hip_decode_host": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "alac_synth_frame": (None, [_u64, _u32, _u32, _u32, _vp]),
+    "alac_synth_pcm": (None, [_u64, _u32, _u32, _u32, _u32, _vp]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libalac_hip.so and bind every symbol of include/alac_hip.h (raises if one is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} is missing: build it with `make -C alac_amd/csrc` (or __graft_entry__.build()); "
+            "the HIP path has no CPU fallback")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def synth_pcm(first_frame, num_frames, fmt):
+    """Deterministic synthetic PCM (alac_synth.c) as a uint8 numpy array, host side, no GPU needed."""
+    p = SYNTH_PATH if os.path.exists(SYNTH_PATH) else LIB_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{SYNTH_PATH} missing: run `make -C alac_amd/csrc`")
+    lib = C.CDLL(p)
+    lib.alac_synth_pcm.argtypes = SIGNATURES["alac_synth_pcm"][1]
+    lib.alac_synth_pcm.restype = None
+    out = np.zeros(num_frames * fmt.packet_bytes, dtype=np.uint8)
+    lib.alac_synth_pcm(first_frame, num_frames, fmt.frame_size, fmt.bit_depth, fmt.num_channels,
+                       out.ctypes.data)
+    return out
+
+
+class AlacError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"alac_hip status {code}: {msg}")
+        self.code = code
+
+
+class Context:
+    """One alac_hip_ctx bound to a device and to torch's current stream on it."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("alac_amd needs a HIP device: no GPU visible and there is no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = _vp()
+        rc = self.lib.alac_hip_create(C.byref(h), device, _vp(self.stream.cuda_stream))
+        if rc != 0:
+            raise AlacError(rc, "alac_hip_create failed")
+        self.h = h
+        self._ws = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.alac_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AlacError(rc, self.lib.alac_hip_last_error(self.h).decode())
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def synchronize(self):
+        self._check(self.lib.alac_hip_synchronize(self.h))
+
+    # ---- encode ----------------------------------------------------------------------------
+    def encode_buffers(self, fmt, num_packets):
+        """Preallocate outputs so a timed loop does no allocation."""
+        t = self.torch
+        cap = int(self.lib.alac_hip_encode_max_output_bytes(C.byref(fmt), num_packets))
+        return dict(out=t.empty(cap, dtype=t.uint8, device=self.device),
+                    sizes=t.empty(num_packets, dtype=t.int32, device=self.device),
+                    offsets=t.empty(num_packets + 1, dtype=t.int64, device=self.device))
+
+    def encode(self, fmt, pcm, num_packets, num_samples=None, seg_first=None, state=None, state_in=False,
+               bufs=None):
+        """pcm: uint8 cuda tensor (num_packets * fmt.packet_bytes).  Returns the buffers dict
+        (out, sizes, offsets); offsets[-1] is the total byte count.  Asynchronous."""
+        t = self.torch
+        assert pcm.is_cuda and pcm.dtype == t.uint8 and pcm.numel() >= num_packets * fmt.packet_bytes
+        nseg = num_packets if seg_first is None else seg_first.numel() - 1
+        bufs = bufs or self.encode_buffers(fmt, num_packets)
+        wsb = int(self.lib.alac_hip_encode_workspace_bytes(C.byref(fmt), num_packets, nseg))
+        ws = self._workspace(wsb)
+        rc = self.lib.alac_hip_encode(
+            self.h, C.byref(fmt), pcm.data_ptr(),
+            None if num_samples is None else num_samples.data_ptr(), num_packets,
+            None if seg_first is None else seg_first.data_ptr(), nseg,
+            None if state is None else state.data_ptr(), 1 if state_in else 0,
+            ws.data_ptr(), ws.numel(), bufs["out"].data_ptr(), bufs["out"].numel(),
+            bufs["sizes"].data_ptr(), bufs["offsets"].data_ptr())
+        self._check(rc)
+        return bufs
+
+    def encode_to_host(self, fmt, pcm, num_packets, **kw):
+        """Convenience for tests: returns (stream bytes ndarray, sizes ndarray)."""
+        b = self.encode(fmt, pcm, num_packets, **kw)
+        self.synchronize()
+        total = int(b["offsets"][-1].item())
+        return b["out"][:total].cpu().numpy(), b["sizes"].cpu().numpy().astype(np.uint32)
+
+    def magic_cookie(self, fmt, max_frame_bytes=0, avg_bit_rate=0):
+        c = np.zeros(24, np.uint8)
+        n = self.lib.alac_hip_magic_cookie(C.byref(fmt), max_frame_bytes, avg_bit_rate, c.ctypes.data)
+        assert n == 24
+        return c
+
+    # ---- decode ----------------------------------------------------------------------------
+    def decode(self, cookie, stream, offsets, num_packets):
+        """stream: uint8 cuda tensor, offsets: int64 cuda tensor [num_packets+1].
+        Returns (pcm uint8 tensor [num_packets*packet_bytes], num_samples int32, status int32)."""
+        t = self.torch
+        ck = np.ascontiguousarray(cookie, np.uint8)
+        fmt = Format()
+        self._check(self.lib.alac_hip_format_from_cookie(ck.ctypes.data, ck.size, C.byref(fmt)))
+        pcm = t.zeros(num_packets * fmt.packet_bytes, dtype=t.uint8, device=self.device)
+        ns = t.zeros(num_packets, dtype=t.int32, device=self.device)
+        st = t.zeros(num_packets, dtype=t.int32, device=self.device)
+        wsb = int(self.lib.alac_hip_decode_workspace_bytes(C.byref(fmt), num_packets))
+        ws = self._workspace(wsb)
+        rc = self.lib.alac_hip_decode(self.h, ck.ctypes.data, ck.size, stream.data_ptr(), offsets.data_ptr(),
+                                      num_packets, ws.data_ptr(), ws.numel(), pcm.data_ptr(), ns.data_ptr(),
+                                      st.data_ptr())
+        self._check(rc)
+        return pcm, ns, st, fmt
+
+    # ---- stage level ------------------------------------------------------------------------
+    def pc_block(self, x, num, coefs, numactive, chanbits, denshift=9, decode=False):
+        """x: int32 cuda [rows, stride]; coefs: int16 cuda [rows, 32] (adapted in place)."""
+        t = self.torch
+        out = t.zeros_like(x)
+        fn = self.lib.alac_hip_unpc_block if decode else self.lib.alac_hip_pc_block
+        self._check(fn(self.h, x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], num,
+                       coefs.data_ptr(), numactive, chanbits, denshift))
+        return out
+
+    def dyn_comp(self, pc, num_samples, bit_size, bytes_stride, mb0=10, pb=40, kb=14):
+        t = self.torch
+        rows = pc.shape[0]
+        bits = t.zeros((rows, bytes_stride), dtype=t.uint8, device=self.device)
+        nb = t.zeros(rows, dtype=t.int32, device=self.device)
+        self._check(self.lib.alac_hip_dyn_comp(self.h, mb0, pb, kb, pc.data_ptr(), rows, pc.shape[1],
+                                               num_samples, bit_size, bits.data_ptr(), bytes_stride,
+                                               nb.data_ptr()))
+        return bits, nb
+
+    def dyn_decomp(self, bits, num_samples, max_size, mb0=10, pb=40, kb=14):
+        t = self.torch
+        rows, stride = bits.shape
+        pc = t.zeros((rows, max(num_samples, 1)), dtype=t.int32, device=self.device)
+        nb = t.zeros(rows, dtype=t.int32, device=self.device)
+        st = t.zeros(rows, dtype=t.int32, device=self.device)
+        self._check(self.lib.alac_hip_dyn_decomp(self.h, mb0, pb, kb, bits.data_ptr(), stride, rows,
+                                                 pc.data_ptr(), pc.shape[1], num_samples, max_size,
+                                                 nb.data_ptr(), st.data_ptr()))
+        return pc, nb, st

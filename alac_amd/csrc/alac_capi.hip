@@ -1,0 +1,476 @@
+// alac_capi.hip — the extern "C" boundary of libalac_hip.so (declared in include/alac_hip.h).
+// Host-side only: argument checks, workspace carving, kernel launches.  No exceptions cross the
+// boundary; every HIP failure becomes one of the reference's int32 status codes.
+#include "alac_hip.h"
+#include "alac_dev.hpp"
+#include "alac_kernels.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace alacdev;
+
+struct alac_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::string err;
+};
+
+namespace {
+
+int32_t fail(alac_hip_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->err = what;
+        if (e != hipSuccess) {
+            ctx->err += ": ";
+            ctx->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+bool format_ok(const alac_hip_format *f)
+{
+    if (!f) return false;
+    if (!(f->bit_depth == 16 || f->bit_depth == 20 || f->bit_depth == 24 || f->bit_depth == 32)) return false;
+    if (f->num_channels < 1 || f->num_channels > 2) return false;
+    if (f->frame_size == 0 || f->frame_size > (1u << 20)) return false;
+    return true;
+}
+
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+struct EncLayout {
+    uint64_t recs, bitWords, pred, total;
+    uint32_t wcap;
+    uint64_t predStride;
+};
+
+EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t numSegments)
+{
+    EncLayout L;
+    // escape size bounds what a compressed element may use (codec/ALACEncoder.cu:459,:538)
+    const uint64_t escapeBits = (uint64_t)f->frame_size * f->bit_depth * f->num_channels + 32 + 16;
+    L.wcap = (uint32_t)((escapeBits + 31) / 32 + 4);
+    const uint64_t lanes = align_up((uint64_t)numSegments * f->num_channels, 64);
+    L.predStride = lanes;
+    uint64_t off = 0;
+    L.recs = off;
+    off = align_up(off + (uint64_t)numPackets * sizeof(PacketRec), 256);
+    L.bitWords = off;
+    off = align_up(off + (uint64_t)numPackets * 2 * L.wcap * 4, 256);
+    L.pred = off;
+    off = align_up(off + (uint64_t)(f->frame_size / 8 + 1) * lanes * 4, 256);
+    L.total = off;
+    return L;
+}
+
+struct DecLayout {
+    uint64_t recs, resid, total;
+};
+
+DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
+{
+    DecLayout L;
+    uint64_t off = 0;
+    L.recs = off;
+    off = align_up(off + (uint64_t)numPackets * sizeof(DecRec), 256);
+    L.resid = off;
+    off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4, 256);
+    L.total = off;
+    return L;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(uint64_t n) { return hipMalloc(&p, n ? n : 4); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int32_t alac_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream)
+{
+    if (!out_ctx) return ALAC_HIP_ParamError;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return ALAC_HIP_ParamError;
+    alac_hip_ctx *c = new (std::nothrow) alac_hip_ctx;
+    if (!c) return ALAC_HIP_MemFullError;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return ALAC_HIP_ParamError;
+    }
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return ALAC_HIP_MemFullError;
+        }
+        c->ownStream = true;
+    }
+    *out_ctx = c;
+    return ALAC_HIP_noErr;
+}
+
+void alac_hip_destroy(alac_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->ownStream && ctx->stream) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+int32_t alac_hip_synchronize(alac_hip_ctx *ctx)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
+    return ALAC_HIP_noErr;
+}
+
+const char *alac_hip_last_error(const alac_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void *alac_hip_stream(const alac_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+uint64_t alac_hip_encode_workspace_bytes(const alac_hip_format *fmt, uint32_t num_packets, uint32_t num_segments)
+{
+    if (!format_ok(fmt)) return 0;
+    return enc_layout(fmt, num_packets, num_segments ? num_segments : num_packets).total;
+}
+
+uint64_t alac_hip_encode_max_output_bytes(const alac_hip_format *fmt, uint32_t num_packets)
+{
+    if (!format_ok(fmt)) return 0;
+    // escape element: 7 + 16 + 32 + N*ch*depth + 3 bits, rounded up; +4 so word stores may overhang
+    const uint64_t per = ((uint64_t)fmt->frame_size * fmt->num_channels * fmt->bit_depth + 58 + 7) / 8;
+    return align_up(per * num_packets + 8, 16);
+}
+
+int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                        const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
+                        uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
+                        uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
+                        uint32_t *d_packet_bytes, uint64_t *d_packet_offsets)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
+    if (num_packets == 0) return ALAC_HIP_noErr;
+    if (!d_pcm || !d_workspace || !d_out || !d_packet_bytes || !d_packet_offsets)
+        return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (!d_seg_first) num_segments = num_packets;
+    if (num_segments == 0 || num_segments > num_packets) return fail(ctx, ALAC_HIP_ParamError, "bad segment count");
+    if (((uintptr_t)d_out & 3) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_pcm & 3))
+        return fail(ctx, ALAC_HIP_ParamError, "misaligned buffer (out/pcm 4 B, workspace 256 B)");
+    const EncLayout L = enc_layout(fmt, num_packets, num_segments);
+    if (workspace_bytes < L.total) return fail(ctx, ALAC_HIP_ParamError, "workspace too small");
+    if (out_capacity < alac_hip_encode_max_output_bytes(fmt, num_packets))
+        return fail(ctx, ALAC_HIP_ParamError, "output capacity below alac_hip_encode_max_output_bytes");
+
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
+    uint8_t *ws = (uint8_t *)d_workspace;
+    EncodeArgs ea;
+    ea.pcm = (const uint8_t *)d_pcm;
+    ea.numSamples = d_num_samples;
+    ea.segFirst = d_seg_first;
+    ea.numSegments = num_segments;
+    ea.frameSize = fmt->frame_size;
+    ea.state = d_state;
+    ea.stateIn = state_in;
+    ea.pred = (int32_t *)(ws + L.pred);
+    ea.predStride = L.predStride;
+    ea.bitWords = (uint32_t *)(ws + L.bitWords);
+    ea.wcap = L.wcap;
+    ea.recs = (PacketRec *)(ws + L.recs);
+    ea.packetBytes = d_packet_bytes;
+    PackArgs pa;
+    pa.pcm = ea.pcm;
+    pa.recs = ea.recs;
+    pa.bitWords = ea.bitWords;
+    pa.wcap = L.wcap;
+    pa.frameSize = fmt->frame_size;
+    pa.offsets = d_packet_offsets;
+    pa.out = d_out;
+    hipError_t e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "encode launch", e);
+    return ALAC_HIP_noErr;
+}
+
+uint32_t alac_hip_magic_cookie(const alac_hip_format *fmt, uint32_t max_frame_bytes, uint32_t avg_bit_rate,
+                               uint8_t *c)
+{
+    if (!format_ok(fmt) || !c) return 0;
+    auto be32 = [](uint8_t *p, uint32_t v) {
+        p[0] = (uint8_t)(v >> 24);
+        p[1] = (uint8_t)(v >> 16);
+        p[2] = (uint8_t)(v >> 8);
+        p[3] = (uint8_t)v;
+    };
+    be32(c + 0, fmt->frame_size);
+    c[4] = 0;  // kALACCompatibleVersion
+    c[5] = (uint8_t)fmt->bit_depth;
+    c[6] = (uint8_t)kPB0;
+    c[7] = (uint8_t)kMB0;
+    c[8] = (uint8_t)kKB0;
+    c[9] = (uint8_t)fmt->num_channels;
+    c[10] = 0;
+    c[11] = 255;  // MAX_RUN_DEFAULT
+    be32(c + 12, max_frame_bytes);
+    be32(c + 16, avg_bit_rate);
+    be32(c + 20, fmt->sample_rate);
+    return 24;
+}
+
+int32_t alac_hip_format_from_cookie(const uint8_t *ck, uint32_t size, alac_hip_format *out)
+{
+    if (!ck || !out) return ALAC_HIP_ParamError;
+    // ALACDecoder::Init skips legacy 'frma' and 'alac' atoms (codec/ALACDecoder.cu:123-134)
+    if (size >= 12 && ck[4] == 'f' && ck[5] == 'r' && ck[6] == 'm' && ck[7] == 'a') {
+        ck += 12;
+        size -= 12;
+    }
+    if (size >= 12 && ck[4] == 'a' && ck[5] == 'l' && ck[6] == 'a' && ck[7] == 'c') {
+        ck += 12;
+        size -= 12;
+    }
+    if (size < 24) return ALAC_HIP_ParamError;
+    if (ck[4] > 0) return ALAC_HIP_ParamError;  // compatibleVersion <= kALACVersion (:153)
+    out->frame_size = ((uint32_t)ck[0] << 24) | ((uint32_t)ck[1] << 16) | ((uint32_t)ck[2] << 8) | ck[3];
+    out->bit_depth = ck[5];
+    out->num_channels = ck[9];
+    out->sample_rate = ((uint32_t)ck[20] << 24) | ((uint32_t)ck[21] << 16) | ((uint32_t)ck[22] << 8) | ck[23];
+    return ALAC_HIP_noErr;
+}
+
+uint64_t alac_hip_decode_workspace_bytes(const alac_hip_format *fmt, uint32_t num_packets)
+{
+    if (!format_ok(fmt)) return 0;
+    return dec_layout(fmt, num_packets).total;
+}
+
+int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size, const uint8_t *d_stream,
+                        const uint64_t *d_packet_offsets, uint32_t num_packets, void *d_workspace,
+                        uint64_t workspace_bytes, uint8_t *d_pcm_out, uint32_t *d_num_samples_out,
+                        int32_t *d_status)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    alac_hip_format fmt;
+    if (alac_hip_format_from_cookie(h_cookie, cookie_size, &fmt) != ALAC_HIP_noErr)
+        return fail(ctx, ALAC_HIP_ParamError, "bad magic cookie");
+    if (!format_ok(&fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format in cookie");
+    if (num_packets == 0) return ALAC_HIP_noErr;
+    if (!d_stream || !d_packet_offsets || !d_workspace || !d_pcm_out || !d_num_samples_out || !d_status)
+        return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (((uintptr_t)d_workspace & 255) || ((uintptr_t)d_pcm_out & 3))
+        return fail(ctx, ALAC_HIP_ParamError, "misaligned buffer");
+    const DecLayout L = dec_layout(&fmt, num_packets);
+    if (workspace_bytes < L.total) return fail(ctx, ALAC_HIP_ParamError, "workspace too small");
+    // skip wrappers again to reach pb/mb/kb
+    const uint8_t *ck = h_cookie;
+    uint32_t size = cookie_size;
+    if (size >= 12 && ck[4] == 'f' && ck[5] == 'r' && ck[6] == 'm' && ck[7] == 'a') { ck += 12; size -= 12; }
+    if (size >= 12 && ck[4] == 'a' && ck[5] == 'l' && ck[6] == 'a' && ck[7] == 'c') { ck += 12; size -= 12; }
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
+    uint8_t *ws = (uint8_t *)d_workspace;
+    DecodeArgs da;
+    da.stream = d_stream;
+    da.offsets = d_packet_offsets;
+    da.numPackets = num_packets;
+    da.frameSize = fmt.frame_size;
+    da.bitDepth = fmt.bit_depth;
+    da.numChannels = fmt.num_channels;
+    da.pb = ck[6];
+    da.mb = ck[7];
+    da.kb = ck[8];
+    da.recs = (DecRec *)(ws + L.recs);
+    da.resid = (int32_t *)(ws + L.resid);
+    da.pcmOut = d_pcm_out;
+    da.numSamplesOut = d_num_samples_out;
+    da.statusOut = d_status;
+    hipError_t e = launch_decode(da, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "decode launch", e);
+    return ALAC_HIP_noErr;
+}
+
+// ---- stage level ---------------------------------------------------------------------------------
+
+int32_t alac_hip_pc_block(alac_hip_ctx *ctx, const int32_t *d_in, int32_t *d_pc, uint32_t num_rows,
+                          uint32_t row_stride, int32_t num, int16_t *d_coefs, int32_t numactive, uint32_t chanbits,
+                          uint32_t denshift)
+{
+    if (!ctx || !d_in || !d_pc) return ALAC_HIP_ParamError;
+    if (numactive < 0 || numactive > 31 || chanbits < 1 || chanbits > 32 || denshift > 15 || num < 0)
+        return fail(ctx, ALAC_HIP_ParamError, "bad pc_block parameters");
+    if (numactive != 0 && numactive != 31 && !d_coefs) return fail(ctx, ALAC_HIP_ParamError, "null coefs");
+    hipError_t e = launch_pc_block(d_in, d_pc, num_rows, row_stride, num, d_coefs, numactive, chanbits, denshift,
+                                   false, ctx->stream);
+    return e == hipSuccess ? ALAC_HIP_noErr : fail(ctx, ALAC_HIP_ParamError, "pc_block launch", e);
+}
+
+int32_t alac_hip_unpc_block(alac_hip_ctx *ctx, const int32_t *d_pc, int32_t *d_out, uint32_t num_rows,
+                            uint32_t row_stride, int32_t num, int16_t *d_coefs, int32_t numactive,
+                            uint32_t chanbits, uint32_t denshift)
+{
+    if (!ctx || !d_pc || !d_out) return ALAC_HIP_ParamError;
+    if (numactive < 0 || numactive > 31 || chanbits < 1 || chanbits > 32 || denshift > 15 || num < 0)
+        return fail(ctx, ALAC_HIP_ParamError, "bad unpc_block parameters");
+    if (numactive != 0 && numactive != 31 && !d_coefs) return fail(ctx, ALAC_HIP_ParamError, "null coefs");
+    hipError_t e = launch_pc_block(d_pc, d_out, num_rows, row_stride, num, d_coefs, numactive, chanbits, denshift,
+                                   true, ctx->stream);
+    return e == hipSuccess ? ALAC_HIP_noErr : fail(ctx, ALAC_HIP_ParamError, "unpc_block launch", e);
+}
+
+int32_t alac_hip_dyn_comp(alac_hip_ctx *ctx, uint32_t mb0, uint32_t pb, uint32_t kb, const int32_t *d_pc,
+                          uint32_t num_rows, uint32_t row_stride, int32_t num_samples, int32_t bit_size,
+                          uint8_t *d_bits, uint32_t bytes_stride, uint32_t *d_num_bits)
+{
+    if (!ctx || !d_pc || !d_num_bits) return ALAC_HIP_ParamError;
+    if (bit_size < 1 || bit_size > 32 || kb < 1 || kb > 16 || num_samples < 0)  // codec/ag_enc.c:268
+        return fail(ctx, ALAC_HIP_ParamError, "bad dyn_comp parameters");
+    if (d_bits && ((bytes_stride & 3) || ((uintptr_t)d_bits & 3)))
+        return fail(ctx, ALAC_HIP_ParamError, "bit buffer must be 4-byte aligned/strided");
+    hipError_t e = launch_dyn_comp(mb0, pb, kb, d_pc, num_rows, row_stride, num_samples, bit_size, d_bits,
+                                   bytes_stride, d_num_bits, ctx->stream);
+    return e == hipSuccess ? ALAC_HIP_noErr : fail(ctx, ALAC_HIP_ParamError, "dyn_comp launch", e);
+}
+
+int32_t alac_hip_dyn_decomp(alac_hip_ctx *ctx, uint32_t mb0, uint32_t pb, uint32_t kb, const uint8_t *d_bits,
+                            uint32_t bytes_stride, uint32_t num_rows, int32_t *d_pc, uint32_t row_stride,
+                            int32_t num_samples, int32_t max_size, uint32_t *d_num_bits, int32_t *d_status)
+{
+    if (!ctx || !d_bits || !d_pc || !d_num_bits || !d_status) return ALAC_HIP_ParamError;
+    if (max_size < 1 || max_size > 32 || kb < 1 || kb > 16 || num_samples < 0)
+        return fail(ctx, ALAC_HIP_ParamError, "bad dyn_decomp parameters");
+    hipError_t e = launch_dyn_decomp(mb0, pb, kb, d_bits, bytes_stride, num_rows, d_pc, row_stride, num_samples,
+                                     max_size, d_num_bits, d_status, ctx->stream);
+    return e == hipSuccess ? ALAC_HIP_noErr : fail(ctx, ALAC_HIP_ParamError, "dyn_decomp launch", e);
+}
+
+// ---- host-buffer convenience ---------------------------------------------------------------------
+
+int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *h_pcm,
+                             uint64_t total_samples, uint32_t segment_packets, int16_t *h_state, int32_t state_in,
+                             uint8_t *h_out, uint64_t out_capacity, uint32_t *h_packet_bytes,
+                             uint64_t *out_total_bytes)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
+    if (out_total_bytes) *out_total_bytes = 0;
+    if (total_samples == 0) return ALAC_HIP_noErr;
+    if (!h_pcm || !h_out || !h_packet_bytes) return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
+
+    const uint32_t bpf = fmt->num_channels * bytes_per_sample(fmt->bit_depth);
+    const uint64_t np64 = (total_samples + fmt->frame_size - 1) / fmt->frame_size;
+    if (np64 > 0x7fffffffull) return fail(ctx, ALAC_HIP_ParamError, "too many packets");
+    const uint32_t np = (uint32_t)np64;
+    const uint32_t nseg = segment_packets ? (np + segment_packets - 1) / segment_packets : 1;
+    std::vector<uint32_t> ns(np, fmt->frame_size), segFirst(nseg + 1);
+    ns[np - 1] = (uint32_t)(total_samples - (uint64_t)(np - 1) * fmt->frame_size);
+    for (uint32_t s = 0; s <= nseg; s++) {
+        uint64_t f = segment_packets ? (uint64_t)s * segment_packets : (s ? np : 0);
+        segFirst[s] = (uint32_t)(f < np ? f : np);
+    }
+    const uint64_t pcmBytes = (uint64_t)np * fmt->frame_size * bpf;  // padded to whole packets
+    const uint64_t inBytes = total_samples * bpf;
+    const uint64_t wsBytes = alac_hip_encode_workspace_bytes(fmt, np, nseg);
+    const uint64_t outMax = alac_hip_encode_max_output_bytes(fmt, np);
+
+    DevBuf dPcm, dNs, dSeg, dState, dWs, dOut, dSizes, dOffs;
+    hipError_t e;
+    if ((e = dPcm.alloc(pcmBytes)) || (e = dNs.alloc(np * 4ull)) || (e = dSeg.alloc((nseg + 1) * 4ull)) ||
+        (e = dState.alloc(nseg * 128ull)) || (e = dWs.alloc(wsBytes)) || (e = dOut.alloc(outMax)) ||
+        (e = dSizes.alloc(np * 4ull)) || (e = dOffs.alloc((np + 1) * 8ull)))
+        return fail(ctx, ALAC_HIP_MemFullError, "hipMalloc", e);
+    hipStream_t st = ctx->stream;
+    if ((e = hipMemsetAsync(dPcm.p, 0, pcmBytes, st)) ||
+        (e = hipMemcpyAsync(dPcm.p, h_pcm, inBytes, hipMemcpyHostToDevice, st)) ||
+        (e = hipMemcpyAsync(dNs.p, ns.data(), np * 4ull, hipMemcpyHostToDevice, st)) ||
+        (e = hipMemcpyAsync(dSeg.p, segFirst.data(), (nseg + 1) * 4ull, hipMemcpyHostToDevice, st)))
+        return fail(ctx, ALAC_HIP_ParamError, "H2D copy", e);
+    if (h_state && state_in)
+        if ((e = hipMemcpyAsync(dState.p, h_state, nseg * 128ull, hipMemcpyHostToDevice, st)))
+            return fail(ctx, ALAC_HIP_ParamError, "H2D state", e);
+    int32_t rc = alac_hip_encode(ctx, fmt, dPcm.p, (const uint32_t *)dNs.p, np, (const uint32_t *)dSeg.p, nseg,
+                                 (int16_t *)dState.p, (h_state && state_in) ? 1 : 0, dWs.p, wsBytes,
+                                 (uint8_t *)dOut.p, outMax, (uint32_t *)dSizes.p, (uint64_t *)dOffs.p);
+    if (rc != ALAC_HIP_noErr) return rc;
+    uint64_t total = 0;
+    if ((e = hipMemcpyAsync(&total, (uint64_t *)dOffs.p + np, 8, hipMemcpyDeviceToHost, st)) ||
+        (e = hipStreamSynchronize(st)))
+        return fail(ctx, ALAC_HIP_ParamError, "encode execution", e);
+    if (total > out_capacity) return fail(ctx, ALAC_HIP_MemFullError, "host output buffer too small");
+    if ((e = hipMemcpyAsync(h_out, dOut.p, total, hipMemcpyDeviceToHost, st)) ||
+        (e = hipMemcpyAsync(h_packet_bytes, dSizes.p, np * 4ull, hipMemcpyDeviceToHost, st)))
+        return fail(ctx, ALAC_HIP_ParamError, "D2H copy", e);
+    if (h_state)
+        if ((e = hipMemcpyAsync(h_state, dState.p, nseg * 128ull, hipMemcpyDeviceToHost, st)))
+            return fail(ctx, ALAC_HIP_ParamError, "D2H state", e);
+    if ((e = hipStreamSynchronize(st))) return fail(ctx, ALAC_HIP_ParamError, "sync", e);
+    if (out_total_bytes) *out_total_bytes = total;
+    return ALAC_HIP_noErr;
+}
+
+int32_t alac_hip_decode_host(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size,
+                             const uint8_t *h_stream, const uint32_t *h_packet_bytes, uint32_t num_packets,
+                             uint8_t *h_pcm_out, uint32_t *h_num_samples_out, int32_t *h_status)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    alac_hip_format fmt;
+    if (alac_hip_format_from_cookie(h_cookie, cookie_size, &fmt) != ALAC_HIP_noErr || !format_ok(&fmt))
+        return fail(ctx, ALAC_HIP_ParamError, "bad magic cookie");
+    if (num_packets == 0) return ALAC_HIP_noErr;
+    if (!h_stream || !h_packet_bytes || !h_pcm_out || !h_num_samples_out || !h_status)
+        return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
+    std::vector<uint64_t> offs(num_packets + 1, 0);
+    for (uint32_t i = 0; i < num_packets; i++) offs[i + 1] = offs[i] + h_packet_bytes[i];
+    const uint64_t total = offs[num_packets];
+    const uint32_t bpf = fmt.num_channels * bytes_per_sample(fmt.bit_depth);
+    const uint64_t pcmBytes = (uint64_t)num_packets * fmt.frame_size * bpf;
+    const uint64_t wsBytes = alac_hip_decode_workspace_bytes(&fmt, num_packets);
+    DevBuf dStream, dOffs, dWs, dPcm, dNs, dSt;
+    hipError_t e;
+    if ((e = dStream.alloc(total + 16)) || (e = dOffs.alloc((num_packets + 1) * 8ull)) || (e = dWs.alloc(wsBytes)) ||
+        (e = dPcm.alloc(pcmBytes)) || (e = dNs.alloc(num_packets * 4ull)) || (e = dSt.alloc(num_packets * 4ull)))
+        return fail(ctx, ALAC_HIP_MemFullError, "hipMalloc", e);
+    hipStream_t st = ctx->stream;
+    if ((e = hipMemcpyAsync(dStream.p, h_stream, total, hipMemcpyHostToDevice, st)) ||
+        (e = hipMemcpyAsync(dOffs.p, offs.data(), (num_packets + 1) * 8ull, hipMemcpyHostToDevice, st)) ||
+        (e = hipMemsetAsync(dPcm.p, 0, pcmBytes, st)))
+        return fail(ctx, ALAC_HIP_ParamError, "H2D copy", e);
+    int32_t rc = alac_hip_decode(ctx, h_cookie, cookie_size, (const uint8_t *)dStream.p, (const uint64_t *)dOffs.p,
+                                 num_packets, dWs.p, wsBytes, (uint8_t *)dPcm.p, (uint32_t *)dNs.p,
+                                 (int32_t *)dSt.p);
+    if (rc != ALAC_HIP_noErr) return rc;
+    if ((e = hipMemcpyAsync(h_pcm_out, dPcm.p, pcmBytes, hipMemcpyDeviceToHost, st)) ||
+        (e = hipMemcpyAsync(h_num_samples_out, dNs.p, num_packets * 4ull, hipMemcpyDeviceToHost, st)) ||
+        (e = hipMemcpyAsync(h_status, dSt.p, num_packets * 4ull, hipMemcpyDeviceToHost, st)) ||
+        (e = hipStreamSynchronize(st)))
+        return fail(ctx, ALAC_HIP_ParamError, "decode execution", e);
+    return ALAC_HIP_noErr;
+}
+
+}  // extern "C"

@@ -1,0 +1,605 @@
+// alac_decode.hip — batch ALAC decode kernels + the batched stage-level entry points.
+//
+// Decode pipeline (packets are independent: coefficients travel in each header):
+//   k_decode_entropy  one lane per packet: element/header parse + dyn_decomp of U then V (V starts
+//                     where U's bits end, so the two channels of a packet are serial here)
+//   k_decode_unpc     one lane per (packet, channel): unpc_block in place
+//   k_decode_unmix    LDS-transposed un-mix + PCM packing, coalesced on both sides
+//
+// Reference: ALACDecoder::Decode codec/ALACDecoder.cu:571-1002, fillWriteBuffer :497-563,
+// dyn_decomp codec/ag_dec.c:272-362, unpc_block codec/dp_dec.c:55-381.
+#include "alac_dev.hpp"
+#include "alac_kernels.hpp"
+
+namespace alacdev {
+
+// ------------------------------------------------------------------------------------------------
+// dyn_decomp (codec/ag_dec.c:272-362; dyn_get_32bit :220-270, dyn_get :171-217), lane-serial.
+// Writes residual c to dst[c * dstStride].  Returns status; *bitsUsed = consumed bits.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t decomp_lane(const uint8_t *base, uint64_t nbytes, uint64_t &pos,
+                                               int32_t *dst, uint64_t dstStride, uint32_t numSamples,
+                                               uint32_t maxSize, uint32_t mb0, uint32_t pb, uint32_t kb)
+{
+    const uint32_t wb = (1u << kb) - 1;
+    const uint64_t maxPos = nbytes * 8;
+    uint32_t mb = mb0, zmode = 0, c = 0;
+    int32_t status = 0;
+    while (c < numSamples) {
+        if (!(pos < maxPos)) {  // :302
+            status = -50;
+            break;
+        }
+        uint32_t m = mb >> kQBShift;
+        uint32_t k = (uint32_t)lg3a(m);
+        k = k > kb ? kb : k;
+        m = (1u << k) - 1;
+
+        uint32_t n;
+        {
+            uint32_t streamlong = peek32(base, nbytes, pos);
+            const uint32_t pre = (uint32_t)lead(~streamlong);
+            if (pre >= kMaxPrefix) {
+                uint64_t q = pos + kMaxPrefix;
+                n = read_bits(base, nbytes, q, maxSize);
+                pos += kMaxPrefix + maxSize;
+            } else {
+                pos += pre + 1;
+                n = pre;
+                if (k != 1) {
+                    streamlong <<= pre + 1;
+                    const uint32_t v = streamlong >> (32 - k);
+                    pos += k - 1;
+                    n = pre * m;
+                    if (v >= 2) {
+                        n += v - 1;
+                        pos += 1;
+                    }
+                }
+            }
+        }
+        const uint32_t nd = n + zmode;
+        const int32_t mult = (-(int32_t)(nd & 1)) | 1;
+        dst[(uint64_t)c * dstStride] = (int32_t)((nd + 1) >> 1) * mult;
+        c++;
+
+        mb = pb * (n + zmode) + mb - ((pb * mb) >> kQBShift);
+        if (n > kMeanClamp) mb = kMeanClamp;
+        zmode = 0;
+
+        if (((mb << 2) < (1u << kQBShift)) && (c < numSamples)) {
+            zmode = 1;
+            k = (uint32_t)(lead(mb) - 24 + (int32_t)((mb + 16u) >> 6));
+            const uint32_t mz = ((1u << k) - 1) & wb;
+            uint32_t streamlong = peek32(base, nbytes, pos);
+            const uint32_t pre = (uint32_t)lead(~streamlong);
+            uint32_t nz;
+            if (pre >= kMaxPrefix) {
+                streamlong <<= kMaxPrefix;
+                nz = streamlong >> (32 - kMaxRunBits);
+                pos += kMaxPrefix + kMaxRunBits;
+            } else {
+                pos += pre + 1;
+                streamlong <<= pre + 1;
+                const uint32_t v = streamlong >> (32 - k);
+                pos += k;
+                nz = pre * mz + v - 1;
+                if (v < 2) {
+                    nz -= (v - 1);
+                    pos -= 1;
+                }
+            }
+            if (!((uint64_t)c + nz <= (uint64_t)numSamples)) {  // :341
+                status = -50;
+                break;
+            }
+            for (uint32_t j = 0; j < nz; j++) {
+                dst[(uint64_t)c * dstStride] = 0;
+                c++;
+            }
+            if (nz >= 65535) zmode = 0;
+            mb = 0;
+        }
+    }
+    if (status == 0 && (pos + 7) / 8 > nbytes) status = -50;  // :359
+    return status;
+}
+
+__global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
+{
+    const uint32_t p = blockIdx.x * 64u + threadIdx.x;
+    if (p >= A.numPackets) return;
+    const uint64_t off = A.offsets[p];
+    const uint64_t nbytes = A.offsets[p + 1] - off;
+    const uint8_t *base = A.stream + off;
+    DecRec *rec = A.recs + p;
+    const uint64_t rs = A.numPackets;  // residual stride between consecutive samples
+    int32_t *resU = A.resid + p;
+    int32_t *resV = A.resid + (uint64_t)A.frameSize * rs + p;
+
+    uint64_t pos = 0;
+    uint32_t numSamples = A.frameSize;
+    int32_t status = 0;
+    bool done = false;
+    rec->numSamples = 0;
+    rec->escape = 0;
+    rec->mixBits = rec->mixRes = 0;
+    rec->bytesShifted = 0;
+    rec->elementChannels = 0;
+    rec->shiftPos = 0;
+
+    while (!done && status == 0) {
+        if (!((pos >> 3) < nbytes)) {  // :615
+            status = -50;
+            break;
+        }
+        const uint32_t tag = read_bits(base, nbytes, pos, 3);
+        switch (tag) {
+        case 0:    // ID_SCE
+        case 3:    // ID_LFE
+        case 1: {  // ID_CPE
+            const uint32_t ech = (tag == 1) ? 2u : 1u;
+            if (ech != A.numChannels) {  // > 2-channel layouts (several elements) are not built yet
+                status = -4;
+                break;
+            }
+            (void)read_bits(base, nbytes, pos, 4);
+            if (read_bits(base, nbytes, pos, 12) != 0) {  // :633 / :768
+                status = -50;
+                break;
+            }
+            const uint32_t hb = read_bits(base, nbytes, pos, 4);
+            const uint32_t partial = hb >> 3, shb = (hb >> 1) & 3, esc = hb & 1;
+            if (shb == 3) {
+                status = -50;
+                break;
+            }
+            uint32_t chanBits = A.bitDepth - shb * 8 + (ech == 2 ? 1 : 0);
+            if (partial) numSamples = read_bits(base, nbytes, pos, 32);
+            if (numSamples > A.frameSize) {
+                status = -50;
+                break;
+            }
+            rec->elementChannels = ech;
+            if (!esc) {
+                const uint32_t mixBits = read_bits(base, nbytes, pos, 8);
+                const int32_t mixRes = (int8_t)read_bits(base, nbytes, pos, 8);
+                for (uint32_t c = 0; c < ech; c++) {
+                    uint32_t b = read_bits(base, nbytes, pos, 8);
+                    rec->c[c].mode = (uint16_t)(b >> 4);
+                    rec->c[c].denShift = (uint16_t)(b & 0xf);
+                    b = read_bits(base, nbytes, pos, 8);
+                    rec->c[c].pbFactor = (uint16_t)(b >> 5);
+                    rec->c[c].num = (uint16_t)(b & 0x1f);
+                    for (uint32_t i = 0; i < (b & 0x1f); i++)
+                        rec->c[c].coefs[i] = (int16_t)read_bits(base, nbytes, pos, 16);
+                }
+                rec->shiftPos = pos;
+                if (shb) pos += (uint64_t)shb * 8 * ech * numSamples;
+                status = decomp_lane(base, nbytes, pos, resU, rs, numSamples, chanBits, A.mb,
+                                     (A.pb * rec->c[0].pbFactor) / 4, A.kb);
+                if (status == 0 && ech == 2)
+                    status = decomp_lane(base, nbytes, pos, resV, rs, numSamples, chanBits, A.mb,
+                                         (A.pb * rec->c[1].pbFactor) / 4, A.kb);
+                rec->mixBits = (int32_t)mixBits;
+                rec->mixRes = mixRes;
+                rec->bytesShifted = shb;
+            } else {
+                // :697-727 / :856-896 uncompressed element
+                chanBits = A.bitDepth;
+                const uint32_t sh = 32 - chanBits;
+                for (uint32_t i = 0; i < numSamples; i++) {
+                    resU[(uint64_t)i * rs] = (int32_t)(read_bits(base, nbytes, pos, chanBits) << sh) >> sh;
+                    if (ech == 2)
+                        resV[(uint64_t)i * rs] = (int32_t)(read_bits(base, nbytes, pos, chanBits) << sh) >> sh;
+                }
+                rec->escape = 1;
+            }
+            rec->numSamples = numSamples;
+            done = true;  // channelIndex >= numChannels, :967
+            break;
+        }
+        case 2:  // ID_CCE
+        case 5:  // ID_PCE
+            status = -50;
+            break;
+        case 4: {  // ID_DSE :1033-1059
+            (void)read_bits(base, nbytes, pos, 4);
+            const uint32_t align = read_bits(base, nbytes, pos, 1);
+            uint32_t count = read_bits(base, nbytes, pos, 8);
+            if (count == 255) count += read_bits(base, nbytes, pos, 8);
+            if (align && (pos & 7)) pos += 8 - (pos & 7);
+            pos += (uint64_t)count * 8;
+            if ((pos + 7) / 8 > nbytes) status = -50;
+            break;
+        }
+        case 6: {  // ID_FIL :1012-1027
+            int32_t count = (int32_t)read_bits(base, nbytes, pos, 4);
+            if (count == 15) count += (int32_t)read_bits(base, nbytes, pos, 8) - 1;
+            pos += (uint64_t)count * 8;
+            if ((pos + 7) / 8 > nbytes) status = -50;
+            break;
+        }
+        default:  // ID_END before any audio element
+            done = true;
+            break;
+        }
+    }
+    rec->status = status;
+    A.statusOut[p] = status;
+    A.numSamplesOut[p] = status == 0 ? rec->numSamples : 0;
+}
+
+// ---- unpc_block, in place over a strided row --------------------------------------------------
+
+template <int NA>
+__device__ __forceinline__ void unpc_fixed(int32_t *row, uint64_t rs, uint32_t num, const int16_t *coefs,
+                                           uint32_t chanshift, uint32_t denshift)
+{
+    Lms<NA> s;
+#pragma unroll
+    for (int k = 0; k < NA; k++) s.a[k] = coefs[k];
+#pragma unroll
+    for (int k = 0; k <= NA; k++) s.h[k] = 0;
+    int32_t dn = num ? row[0] : 0;
+    for (uint32_t j = 0; j < num; j++) {
+        const int32_t del = dn;
+        if (j + 1 < num) dn = row[(uint64_t)(j + 1) * rs];
+        int32_t out;
+        if (j == 0) {
+            out = del;
+            lms_push<NA>(s, out);
+        } else if (j <= (uint32_t)NA) {
+            out = sext(del + s.h[0], chanshift);
+            lms_push<NA>(s, out);
+        } else {
+            out = lms_step_dec<NA>(s, del, chanshift, denshift);
+        }
+        row[(uint64_t)j * rs] = out;
+    }
+}
+
+// any tap count 1..30 (codec/dp_dec.c:335-380); history and coefficients in private memory
+__device__ void unpc_general(int32_t *row, uint64_t rs, uint32_t num, const int16_t *coefs, uint32_t na,
+                             uint32_t chanshift, uint32_t denshift, int16_t *coefsOut = nullptr)
+{
+    int32_t a[32], h[33];
+    for (uint32_t k = 0; k < 32; k++) a[k] = k < na ? coefs[k] : 0;
+    for (uint32_t k = 0; k < 33; k++) h[k] = 0;
+    const int32_t denhalf = denshift ? (1 << (denshift - 1)) : 0;
+    for (uint32_t j = 0; j < num; j++) {
+        const int32_t del = row[(uint64_t)j * rs];
+        int32_t out;
+        if (j == 0) {
+            out = del;
+        } else if (j <= na) {
+            out = sext(del + h[0], chanshift);
+        } else {
+            const int32_t top = h[na];
+            int32_t sum = 0;
+            for (uint32_t k = 0; k < na; k++) sum += a[k] * (h[k] - top);
+            out = sext(del + top + ((sum + denhalf) >> denshift), chanshift);
+            const int32_t sg = sign_of(del);
+            int32_t del0 = del;
+            if (sg > 0) {
+                for (int32_t k = (int32_t)na - 1; k >= 0; k--) {
+                    const int32_t dd = top - h[k];
+                    const int32_t sgn = sign_of(dd);
+                    a[k] = (int16_t)(a[k] - sgn);
+                    del0 -= ((int32_t)na - k) * ((sgn * dd) >> denshift);
+                    if (del0 <= 0) break;
+                }
+            } else if (sg < 0) {
+                for (int32_t k = (int32_t)na - 1; k >= 0; k--) {
+                    const int32_t dd = top - h[k];
+                    const int32_t sgn = sign_of(dd);
+                    a[k] = (int16_t)(a[k] + sgn);
+                    del0 -= ((int32_t)na - k) * ((-sgn * dd) >> denshift);
+                    if (del0 >= 0) break;
+                }
+            }
+        }
+        for (uint32_t k = na; k > 0; k--) h[k] = h[k - 1];
+        h[0] = out;
+        row[(uint64_t)j * rs] = out;
+    }
+    if (coefsOut)
+        for (uint32_t k = 0; k < na; k++) coefsOut[k] = (int16_t)a[k];
+}
+
+// numactive == 31: first-order (codec/dp_dec.c:74-95)
+__device__ __forceinline__ void unpc_first_order(int32_t *row, uint64_t rs, uint32_t num, uint32_t chanshift)
+{
+    if (!num) return;
+    int32_t prev = row[0];
+    for (uint32_t j = 1; j < num; j++) {
+        prev = sext(row[(uint64_t)j * rs] + prev, chanshift);
+        row[(uint64_t)j * rs] = prev;
+    }
+}
+
+__device__ __forceinline__ void unpc_any(int32_t *row, uint64_t rs, uint32_t num, const int16_t *coefs,
+                                         uint32_t na, uint32_t chanbits, uint32_t denshift)
+{
+    const uint32_t chanshift = 32 - chanbits;
+    if (na == 0) return;  // copy, in place
+    if (na == 31)
+        unpc_first_order(row, rs, num, chanshift);
+    else if (na == 4)
+        unpc_fixed<4>(row, rs, num, coefs, chanshift, denshift);
+    else if (na == 8)
+        unpc_fixed<8>(row, rs, num, coefs, chanshift, denshift);
+    else
+        unpc_general(row, rs, num, coefs, na, chanshift, denshift);
+}
+
+__global__ __launch_bounds__(64) void k_decode_unpc(DecodeArgs A)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (gid >= (uint64_t)A.numPackets * A.numChannels) return;
+    const uint32_t ch = (uint32_t)(gid / A.numPackets);
+    const uint32_t p = (uint32_t)(gid % A.numPackets);
+    const DecRec *rec = A.recs + p;
+    if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return;
+    const uint32_t chanbits = A.bitDepth - rec->bytesShifted * 8 + (rec->elementChannels == 2 ? 1 : 0);
+    int32_t *row = A.resid + (uint64_t)ch * A.frameSize * A.numPackets + p;
+    const DecChan &c = rec->c[ch];
+    // :829-838: mode != 0 runs the first-order pass first
+    if (c.mode != 0) unpc_first_order(row, A.numPackets, rec->numSamples, 32 - chanbits);
+    unpc_any(row, A.numPackets, rec->numSamples, c.coefs, c.num, chanbits, c.denShift);
+}
+
+// ---- un-mix + pack (gpu_unmixNN / gpu_copyPredictorToNN, codec/ALACDecoder.cu:193-495) --------
+
+template <int DEPTH>
+__device__ __forceinline__ void store_sample(uint8_t *p, int32_t x)
+{
+    if constexpr (DEPTH == 16) {
+        *(int16_t *)p = (int16_t)x;
+    } else if constexpr (DEPTH == 32) {
+        *(int32_t *)p = x;
+    } else {
+        if constexpr (DEPTH == 20) x = (int32_t)((uint32_t)x << 4);
+        p[0] = (uint8_t)x;
+        p[1] = (uint8_t)(x >> 8);
+        p[2] = (uint8_t)(x >> 16);
+    }
+}
+
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(256) void k_decode_unmix(DecodeArgs A)
+{
+    __shared__ int32_t tu[64][65];
+    __shared__ int32_t tv[CH == 2 ? 64 : 1][65];
+    const uint32_t tileP = blockIdx.x * 64u, tileJ = blockIdx.y * 64u;
+    const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+
+    // load: consecutive lanes = consecutive packets (the residual layout's fast axis)
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t jj = grp + 4 * i;
+        const uint32_t j = tileJ + jj, p = tileP + lane;
+        int32_t u = 0, v = 0;
+        if (p < A.numPackets && j < A.frameSize) {
+            u = A.resid[(uint64_t)j * A.numPackets + p];
+            if constexpr (CH == 2) v = A.resid[((uint64_t)A.frameSize + j) * A.numPackets + p];
+        }
+        tu[jj][lane] = u;
+        if constexpr (CH == 2) tv[jj][lane] = v;
+    }
+    __syncthreads();
+
+    constexpr uint32_t BPS = bytes_per_sample(DEPTH);
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t pp = grp + 4 * i;
+        const uint32_t p = tileP + pp, j = tileJ + lane;
+        if (p >= A.numPackets) continue;
+        const DecRec *rec = A.recs + p;
+        if (rec->status != 0 || j >= rec->numSamples) continue;
+        const uint32_t shb = rec->bytesShifted;
+        uint8_t *op = A.pcmOut + ((uint64_t)p * A.frameSize + j) * CH * BPS;
+        int32_t l, r = 0;
+        if constexpr (CH == 2) {
+            const int32_t u = tu[lane][pp], v = tv[lane][pp];
+            if (rec->mixRes != 0) {
+                l = u + v - ((rec->mixRes * v) >> rec->mixBits);
+                r = l - v;
+            } else {
+                l = u;
+                r = v;
+            }
+        } else {
+            l = tu[lane][pp];
+        }
+        if (shb != 0 && DEPTH >= 24) {
+            const uint8_t *base = A.stream + A.offsets[p];
+            const uint64_t nbytes = A.offsets[p + 1] - A.offsets[p];
+            uint64_t sp = rec->shiftPos + (uint64_t)j * CH * shb * 8;
+            l = (int32_t)(((uint32_t)l << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
+            if constexpr (CH == 2) r = (int32_t)(((uint32_t)r << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
+        }
+        store_sample<DEPTH>(op, l);
+        if constexpr (CH == 2) store_sample<DEPTH>(op + BPS, r);
+    }
+}
+
+template <int DEPTH>
+static void launch_unmix_depth(const DecodeArgs &da, hipStream_t st)
+{
+    dim3 grid((da.numPackets + 63) / 64, (da.frameSize + 63) / 64);
+    if (da.numChannels == 2)
+        hipLaunchKernelGGL((k_decode_unmix<DEPTH, 2>), grid, dim3(256), 0, st, da);
+    else
+        hipLaunchKernelGGL((k_decode_unmix<DEPTH, 1>), grid, dim3(256), 0, st, da);
+}
+
+hipError_t launch_decode(const DecodeArgs &da, hipStream_t st)
+{
+    if (da.numPackets == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_decode_entropy, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, da);
+    const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
+    hipLaunchKernelGGL(k_decode_unpc, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, da);
+    switch (da.bitDepth) {
+    case 16: launch_unmix_depth<16>(da, st); break;
+    case 20: launch_unmix_depth<20>(da, st); break;
+    case 24: launch_unmix_depth<24>(da, st); break;
+    case 32: launch_unmix_depth<32>(da, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level batched entry points (one lane per row)
+// ------------------------------------------------------------------------------------------------
+
+// pc_block for any numactive (codec/dp_enc.c:77-388), general loop
+__device__ void pc_general(const int32_t *in, int32_t *pc, int32_t num, int16_t *coefs, int32_t na,
+                           uint32_t chanbits, uint32_t denshift)
+{
+    const uint32_t chanshift = 32 - chanbits;
+    const int32_t denhalf = denshift ? (1 << (denshift - 1)) : 0;
+    pc[0] = in[0];
+    if (na == 0) {
+        for (int32_t j = 1; j < num; j++) pc[j] = in[j];
+        return;
+    }
+    if (na == 31) {
+        for (int32_t j = 1; j < num; j++) pc[j] = sext(in[j] - in[j - 1], chanshift);
+        return;
+    }
+    for (int32_t j = 1; j <= na; j++) pc[j] = sext(in[j] - in[j - 1], chanshift);
+    int32_t a[32];
+    for (int32_t k = 0; k < 32; k++) a[k] = k < na ? coefs[k] : 0;
+    for (int32_t j = na + 1; j < num; j++) {
+        const int32_t top = in[j - na - 1];
+        const int32_t *pin = in + j - 1;
+        int32_t sum = 0;
+        for (int32_t k = 0; k < na; k++) sum -= a[k] * (top - pin[-k]);
+        const int32_t del = sext(in[j] - top - ((sum + denhalf) >> denshift), chanshift);
+        pc[j] = del;
+        int32_t del0 = del;
+        const int32_t sg = sign_of(del);
+        if (sg > 0) {
+            for (int32_t k = na - 1; k >= 0; k--) {
+                const int32_t dd = top - pin[-k];
+                const int32_t sgn = sign_of(dd);
+                a[k] = (int16_t)(a[k] - sgn);
+                del0 -= (na - k) * ((sgn * dd) >> denshift);
+                if (del0 <= 0) break;
+            }
+        } else if (sg < 0) {
+            for (int32_t k = na - 1; k >= 0; k--) {
+                const int32_t dd = top - pin[-k];
+                const int32_t sgn = sign_of(dd);
+                a[k] = (int16_t)(a[k] + sgn);
+                del0 -= (na - k) * ((-sgn * dd) >> denshift);
+                if (del0 >= 0) break;
+            }
+        }
+    }
+    for (int32_t k = 0; k < na; k++) coefs[k] = (int16_t)a[k];
+}
+
+__global__ __launch_bounds__(64) void k_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride,
+                                                 int32_t num, int16_t *coefs, int32_t na, uint32_t chanbits,
+                                                 uint32_t denshift)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= rows) return;
+    pc_general(in + (uint64_t)r * stride, pc + (uint64_t)r * stride, num, coefs + (uint64_t)r * 32, na, chanbits,
+               denshift);
+}
+
+__global__ __launch_bounds__(64) void k_unpc_block(const int32_t *pc, int32_t *out, uint32_t rows, uint32_t stride,
+                                                   int32_t num, int16_t *coefs, int32_t na, uint32_t chanbits,
+                                                   uint32_t denshift)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= rows) return;
+    const int32_t *src = pc + (uint64_t)r * stride;
+    int32_t *dst = out + (uint64_t)r * stride;
+    if (src != dst)
+        for (int32_t j = 0; j < num; j++) dst[j] = src[j];
+    int16_t *c = coefs + (uint64_t)r * 32;
+    if (na == 31)
+        unpc_first_order(dst, 1, (uint32_t)num, 32 - chanbits);
+    else if (na != 0)
+        unpc_general(dst, 1, (uint32_t)num, c, (uint32_t)na, 32 - chanbits, denshift, c);
+}
+
+__global__ __launch_bounds__(64) void k_dyn_comp(uint32_t mb0, uint32_t pb, uint32_t kb, const int32_t *pc,
+                                                 uint32_t rows, uint32_t stride, int32_t numSamples, int32_t bitSize,
+                                                 uint32_t *words, uint32_t wcap, uint32_t *numBits)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= rows) return;
+    const int32_t *src = pc + (uint64_t)r * stride;
+    Golomb g;
+    gol_reset(g, mb0, pb, kb);
+    g.wp = words ? words + (uint64_t)r * wcap : nullptr;
+    g.wcap = words ? wcap : 0;
+    for (int32_t j = 0; j < numSamples; j++) gol_sym<true>(g, src[j], j + 1 == numSamples, (uint32_t)bitSize);
+    gol_flush<true>(g);
+    numBits[r] = g.bits;
+}
+
+// words (MSB-first uint32) -> bytes in place: byte-swap each word
+__global__ void k_bswap_words(uint32_t *w, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = __builtin_bswap32(w[i]);
+}
+
+__global__ __launch_bounds__(64) void k_dyn_decomp(uint32_t mb0, uint32_t pb, uint32_t kb, const uint8_t *bits,
+                                                   uint32_t bytesStride, uint32_t rows, int32_t *pc, uint32_t stride,
+                                                   int32_t numSamples, int32_t maxSize, uint32_t *numBits,
+                                                   int32_t *status)
+{
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= rows) return;
+    uint64_t pos = 0;
+    const int32_t st = decomp_lane(bits + (uint64_t)r * bytesStride, bytesStride, pos, pc + (uint64_t)r * stride, 1,
+                                   (uint32_t)numSamples, (uint32_t)maxSize, mb0, pb, kb);
+    numBits[r] = (uint32_t)pos;
+    status[r] = st;
+}
+
+hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
+                           int16_t *coefs, int32_t numactive, uint32_t chanbits, uint32_t denshift, bool decode,
+                           hipStream_t st)
+{
+    if (rows == 0) return hipSuccess;
+    if (decode)
+        hipLaunchKernelGGL(k_unpc_block, dim3((rows + 63) / 64), dim3(64), 0, st, in, pc, rows, stride, num, coefs,
+                           numactive, chanbits, denshift);
+    else
+        hipLaunchKernelGGL(k_pc_block, dim3((rows + 63) / 64), dim3(64), 0, st, in, pc, rows, stride, num, coefs,
+                           numactive, chanbits, denshift);
+    return hipGetLastError();
+}
+
+hipError_t launch_dyn_comp(uint32_t mb0, uint32_t pb, uint32_t kb, const int32_t *pc, uint32_t rows, uint32_t stride,
+                           int32_t numSamples, int32_t bitSize, uint8_t *bits, uint32_t bytesStride,
+                           uint32_t *numBits, hipStream_t st)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dyn_comp, dim3((rows + 63) / 64), dim3(64), 0, st, mb0, pb, kb, pc, rows, stride, numSamples,
+                       bitSize, (uint32_t *)bits, bytesStride / 4, numBits);
+    if (bits) {
+        const uint64_t n = (uint64_t)rows * (bytesStride / 4);
+        hipLaunchKernelGGL(k_bswap_words, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint32_t *)bits, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_dyn_decomp(uint32_t mb0, uint32_t pb, uint32_t kb, const uint8_t *bits, uint32_t bytesStride,
+                             uint32_t rows, int32_t *pc, uint32_t stride, int32_t numSamples, int32_t maxSize,
+                             uint32_t *numBits, int32_t *status, hipStream_t st)
+{
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dyn_decomp, dim3((rows + 63) / 64), dim3(64), 0, st, mb0, pb, kb, bits, bytesStride, rows, pc,
+                       stride, numSamples, maxSize, numBits, status);
+    return hipGetLastError();
+}
+
+}  // namespace alacdev

@@ -1,0 +1,99 @@
+// alac_kernels.hpp — argument blocks and launchers shared by the kernels and the C-ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace alacdev {
+
+// per-channel part of a packet record
+struct ChanRec {
+    uint32_t bits;      // entropy-coded bits of this channel
+    uint16_t num;       // numU / numV
+    uint16_t pad;
+    int16_t coefs[8];   // header coefficients (row state before the final pass)
+};
+// one per packet, written by the encode kernel, read by the packer
+struct PacketRec {
+    uint32_t numSamples;
+    uint32_t escape;
+    uint32_t mixRes;
+    uint32_t totalBits;
+    ChanRec c[2];
+};
+static_assert(sizeof(PacketRec) == 64, "PacketRec layout");
+
+struct EncodeArgs {
+    const uint8_t *pcm;
+    const uint32_t *numSamples;  // nullable
+    const uint32_t *segFirst;    // nullable
+    uint32_t numSegments;
+    uint32_t frameSize;
+    int16_t *state;              // nullable
+    int32_t stateIn;
+    int32_t *pred;               // [frameSize/8][predStride] search residual scratch
+    uint64_t predStride;
+    uint32_t *bitWords;          // [packet][2][wcap] per-channel bit strings
+    uint32_t wcap;
+    PacketRec *recs;
+    uint32_t *packetBytes;
+};
+
+struct PackArgs {
+    const uint8_t *pcm;
+    const PacketRec *recs;
+    const uint32_t *bitWords;
+    uint32_t wcap;
+    uint32_t frameSize;
+    const uint64_t *offsets;
+    uint8_t *out;
+};
+
+hipError_t launch_encode(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
+                         uint32_t numPackets, hipStream_t st);
+
+// ---- decode ----
+struct DecChan {
+    uint16_t mode, denShift, pbFactor, num;
+    int16_t coefs[32];
+};
+struct DecRec {
+    uint32_t numSamples;
+    uint32_t escape;
+    int32_t mixBits, mixRes;
+    uint32_t bytesShifted;
+    uint32_t elementChannels;  // 1 (SCE/LFE) or 2 (CPE)
+    uint64_t shiftPos;         // bit position of the shift-off section inside the packet
+    int32_t status;
+    uint32_t pad;
+    DecChan c[2];
+};
+
+struct DecodeArgs {
+    const uint8_t *stream;
+    const uint64_t *offsets;
+    uint32_t numPackets;
+    uint32_t frameSize, bitDepth, numChannels;
+    uint32_t mb, pb, kb;
+    DecRec *recs;
+    int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
+    uint8_t *pcmOut;
+    uint32_t *numSamplesOut;
+    int32_t *statusOut;
+};
+
+hipError_t launch_decode(const DecodeArgs &da, hipStream_t st);
+
+// ---- stage-level ----
+hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
+                           int16_t *coefs, int32_t numactive, uint32_t chanbits, uint32_t denshift,
+                           bool decode, hipStream_t st);
+hipError_t launch_dyn_comp(uint32_t mb0, uint32_t pb, uint32_t kb, const int32_t *pc, uint32_t rows,
+                           uint32_t stride, int32_t numSamples, int32_t bitSize, uint8_t *bits,
+                           uint32_t bytesStride, uint32_t *numBits, hipStream_t st);
+hipError_t launch_dyn_decomp(uint32_t mb0, uint32_t pb, uint32_t kb, const uint8_t *bits,
+                             uint32_t bytesStride, uint32_t rows, int32_t *pc, uint32_t stride,
+                             int32_t numSamples, int32_t maxSize, uint32_t *numBits, int32_t *status,
+                             hipStream_t st);
+
+}  // namespace alacdev

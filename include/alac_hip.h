@@ -1,0 +1,172 @@
+/*
+ * alac_hip.h — C-ABI of the MI355X-native ALAC hot path (libalac_hip.so).
+ *
+ * Plain pointers and sizes only.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree dark-Stallion/alac).  All `d_` pointers are device
+ * (HBM) pointers on the context's device; `h_` pointers are host pointers.  Calls are enqueued on
+ * the context's HIP stream and are asynchronous unless stated otherwise.  Return value is the
+ * reference's int32 status convention: 0 = ALAC_noErr (codec/ALACBitUtilities.h:51-54),
+ * -50 = kALAC_ParamError, -108 = kALAC_MemFullError, -4 = kALAC_UnimplementedError
+ * (codec/ALACAudioTypes.h:54-60).  HIP runtime failures map to -108 (allocation) or -50.
+ */
+#ifndef ALAC_HIP_H
+#define ALAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    ALAC_HIP_noErr = 0,
+    ALAC_HIP_UnimplementedError = -4,
+    ALAC_HIP_ParamError = -50,
+    ALAC_HIP_MemFullError = -108
+};
+
+/* Number of int16 values of persistent encoder state per segment: the predictor rows the search
+ * touches, [U row 3][U row 7][V row 3][V row 7] x 16 coefficients — the live subset of
+ * ALACEncoder::mCoefsU/V (codec/ALACEncoder.h:89-90, rows numUV-1 of codec/ALACEncoder.cu:361,429). */
+#define ALAC_HIP_STATE_INT16 64
+
+typedef struct alac_hip_ctx alac_hip_ctx;
+
+/* What InitializeEncoder derives from AudioFormatDescription (codec/ALACEncoder.cu:1457-1479)
+ * plus SetFrameSize (codec/ALACEncoder.h:47). */
+typedef struct alac_hip_format {
+    uint32_t frame_size;   /* sample-frames per packet; kALACDefaultFramesPerPacket = 4096 */
+    uint32_t bit_depth;    /* 16, 20, 24 or 32 (mFormatFlags 1..4) */
+    uint32_t num_channels; /* 1 (ID_SCE) or 2 (ID_CPE) */
+    uint32_t sample_rate;  /* only carried into the magic cookie */
+} alac_hip_format;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Number of HIP devices visible; < 0 on failure. */
+int32_t alac_hip_device_count(void);
+
+/* Create a context bound to `device`.  `stream` is a hipStream_t to enqueue on (NULL = a stream
+ * the context creates and owns).  Replaces the implicit default-stream/device-0 use of the fork
+ * (codec/ALACEncoder.cu:1494-1512). */
+int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream);
+void alac_hip_destroy(alac_hip_ctx *ctx);
+/* Block until everything enqueued on the context's stream has completed
+ * (the cudaDeviceSynchronize of codec/ALACEncoder.cu:1448). */
+int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
+/* Text of the last HIP/parameter error on this context ("" if none). */
+const char *alac_hip_last_error(const alac_hip_ctx *ctx);
+/* The stream the context enqueues on (hipStream_t as void*), for event timing by the caller. */
+void *alac_hip_stream(const alac_hip_ctx *ctx);
+
+/* ---- batch encode: replaces InitializeSampling + the per-packet Encode loop ----------------
+ * (codec/ALACEncoder.cu:1385-1451, :973-1057, :290-558, :749-806, :812-963; the stage calls
+ *  pc_block codec/dp_enc.c:77, dyn_comp codec/ag_enc.c:249, mixNN codec/matrix_enc.cu:101-425). */
+
+/* Bytes of device scratch alac_hip_encode needs for this shape. */
+uint64_t alac_hip_encode_workspace_bytes(const alac_hip_format *fmt, uint32_t num_packets,
+                                         uint32_t num_segments);
+/* Upper bound of the packed output of num_packets packets (every packet escaped + header). */
+uint64_t alac_hip_encode_max_output_bytes(const alac_hip_format *fmt, uint32_t num_packets);
+
+/*
+ * Encode num_packets packets.
+ *   d_pcm            packed little-endian interleaved PCM; packet p starts at byte
+ *                    p * frame_size * num_channels * bytes_per_sample (convert-utility/main.cu:509)
+ *   d_num_samples    [num_packets] sample-frames in each packet (<= frame_size), or NULL = all full
+ *                    (the outBytes[] of InitializeSampling, in samples)
+ *   d_seg_first      [num_segments + 1] first packet index of each segment (a segment = a run of
+ *                    packets chained through the coefficient state), or NULL =
+ *                    every packet is its own segment (state = init_coefs, codec/dp_enc.c:49-60)
+ *   d_state          [num_segments][ALAC_HIP_STATE_INT16] coefficient rows; read as the initial
+ *                    state when state_in != 0, always written with the final state when non-NULL
+ *   d_out            packets written back to back (each byte-aligned, codec/ALACEncoder.cu:1039)
+ *   d_packet_bytes   [num_packets] size of each packet (the *ioNumBytes of Encode)
+ *   d_packet_offsets [num_packets + 1] exclusive scan of the sizes; last entry = total bytes
+ * Returns ParamError for an unsupported format or a too-small workspace/output.
+ */
+int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                        const uint32_t *d_num_samples, uint32_t num_packets,
+                        const uint32_t *d_seg_first, uint32_t num_segments, int16_t *d_state,
+                        int32_t state_in, void *d_workspace, uint64_t workspace_bytes,
+                        uint8_t *d_out, uint64_t out_capacity, uint32_t *d_packet_bytes,
+                        uint64_t *d_packet_offsets);
+
+/* 24-byte magic cookie (ALACSpecificConfig, big-endian): GetConfig/GetMagicCookie
+ * (codec/ALACEncoder.cu:1082-1140) for <= 2 channels.  Host-only, no device work. */
+uint32_t alac_hip_magic_cookie(const alac_hip_format *fmt, uint32_t max_frame_bytes,
+                               uint32_t avg_bit_rate, uint8_t *h_cookie24);
+
+/* ---- batch decode: replaces ALACDecoder::Decode + fillWriteBuffer ---------------------------
+ * (codec/ALACDecoder.cu:571-1002, :497-563; dyn_decomp codec/ag_dec.c:272, unpc_block
+ *  codec/dp_dec.c:55, gpu_unmixNN codec/ALACDecoder.cu:193-383). */
+
+uint64_t alac_hip_decode_workspace_bytes(const alac_hip_format *fmt, uint32_t num_packets);
+
+/*
+ * Decode num_packets packets (independent: coefficients travel in each packet header).
+ *   h_cookie/size     magic cookie as stored in the CAF 'kuki' chunk (ALACDecoder::Init,
+ *                     codec/ALACDecoder.cu:109-190; legacy 'frma'/'alac' wrappers are skipped)
+ *   d_stream          packets back to back
+ *   d_packet_offsets  [num_packets + 1] byte offset of each packet in d_stream
+ *   d_pcm_out         packet p is written at p * frame_size * num_channels * bytes_per_sample
+ *   d_num_samples_out [num_packets] decoded sample-frames per packet (outNumSamples of Decode)
+ *   d_status          [num_packets] per-packet status (0 or kALAC_ParamError)
+ */
+int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size,
+                        const uint8_t *d_stream, const uint64_t *d_packet_offsets,
+                        uint32_t num_packets, void *d_workspace, uint64_t workspace_bytes,
+                        uint8_t *d_pcm_out, uint32_t *d_num_samples_out, int32_t *d_status);
+
+/* Parse a magic cookie into a format (host only). */
+int32_t alac_hip_format_from_cookie(const uint8_t *h_cookie, uint32_t cookie_size,
+                                    alac_hip_format *out_fmt);
+
+/* ---- stage-level entry points (device buffers), the extern "C" surface of
+ *      codec/dplib.h:49-55, codec/aglib.h:70-74, codec/matrixlib.h:41-60, batched -------------- */
+
+/* pc_block over num_rows independent rows: row r reads d_in + r*row_stride (int32), writes
+ * d_pc + r*row_stride (positions < num), adapts d_coefs + r*32 (int16, numactive used) in place
+ * (codec/dp_enc.c:77).  row_stride must cover max(num, numactive + 1) readable samples. */
+int32_t alac_hip_pc_block(alac_hip_ctx *ctx, const int32_t *d_in, int32_t *d_pc, uint32_t num_rows,
+                          uint32_t row_stride, int32_t num, int16_t *d_coefs, int32_t numactive,
+                          uint32_t chanbits, uint32_t denshift);
+/* unpc_block, same layout (codec/dp_dec.c:55). */
+int32_t alac_hip_unpc_block(alac_hip_ctx *ctx, const int32_t *d_pc, int32_t *d_out,
+                            uint32_t num_rows, uint32_t row_stride, int32_t num, int16_t *d_coefs,
+                            int32_t numactive, uint32_t chanbits, uint32_t denshift);
+/* dyn_comp over num_rows rows with AG params (mb0, pb, kb): row r codes num_samples residuals of
+ * d_pc + r*row_stride into d_bits + r*bytes_stride starting at bit 0; bit counts to d_num_bits
+ * (codec/ag_enc.c:249).  d_bits may be NULL to count only. */
+int32_t alac_hip_dyn_comp(alac_hip_ctx *ctx, uint32_t mb0, uint32_t pb, uint32_t kb,
+                          const int32_t *d_pc, uint32_t num_rows, uint32_t row_stride,
+                          int32_t num_samples, int32_t bit_size, uint8_t *d_bits,
+                          uint32_t bytes_stride, uint32_t *d_num_bits);
+/* dyn_decomp, inverse layout (codec/ag_dec.c:272); per-row status to d_status. */
+int32_t alac_hip_dyn_decomp(alac_hip_ctx *ctx, uint32_t mb0, uint32_t pb, uint32_t kb,
+                            const uint8_t *d_bits, uint32_t bytes_stride, uint32_t num_rows,
+                            int32_t *d_pc, uint32_t row_stride, int32_t num_samples,
+                            int32_t max_size, uint32_t *d_num_bits, int32_t *d_status);
+
+/* ---- host-buffer convenience (synchronous; does its own H2D/D2H and scratch) -----------------
+ * What ALACEncoder::Encode / ALACDecoder::Decode callers with host buffers use
+ * (convert-utility/main.cu:558, :719). */
+int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *h_pcm,
+                             uint64_t total_samples, uint32_t segment_packets, int16_t *h_state,
+                             int32_t state_in, uint8_t *h_out, uint64_t out_capacity,
+                             uint32_t *h_packet_bytes, uint64_t *out_total_bytes);
+int32_t alac_hip_decode_host(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size,
+                             const uint8_t *h_stream, const uint32_t *h_packet_bytes,
+                             uint32_t num_packets, uint8_t *h_pcm_out, uint32_t *h_num_samples_out,
+                             int32_t *h_status);
+
+/* ---- deterministic synthetic PCM, host side --------------------------------- */
+void alac_synth_frame(uint64_t frame_index, uint32_t num_samples, uint32_t bit_depth,
+                      uint32_t channels, uint8_t *h_out);
+void alac_synth_pcm(uint64_t first_frame, uint32_t num_frames, uint32_t frame_size,
+                    uint32_t bit_depth, uint32_t channels, uint8_t *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALAC_HIP_H */
