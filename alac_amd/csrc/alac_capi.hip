@@ -18,6 +18,11 @@ struct alac_hip_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     std::string err;
+    // optional per-kernel timing: 4 events per encode call (before encode, after encode, after
+    // scan, after pack), recorded on `stream`
+    bool profile = false;
+    std::vector<hipEvent_t> events;
+    uint32_t profCalls = 0;
 };
 
 namespace {
@@ -135,6 +140,8 @@ int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream)
 void alac_hip_destroy(alac_hip_ctx *ctx)
 {
     if (!ctx) return;
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    ctx->events.clear();
     if (ctx->ownStream && ctx->stream) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -213,8 +220,47 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
     pa.frameSize = fmt->frame_size;
     pa.offsets = d_packet_offsets;
     pa.out = d_out;
-    hipError_t e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream);
+    hipEvent_t *ev = nullptr;
+    if (ctx->profile && (uint64_t)(ctx->profCalls + 1) * 4 <= ctx->events.size()) ev = &ctx->events[ctx->profCalls++ * 4];
+    hipError_t e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream, ev);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "encode launch", e);
+    return ALAC_HIP_noErr;
+}
+
+int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
+    while (ctx->events.size() < (size_t)max_calls * 4) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return fail(ctx, ALAC_HIP_MemFullError, "hipEventCreate");
+        ctx->events.push_back(e);
+    }
+    ctx->profCalls = 0;
+    ctx->profile = max_calls != 0;
+    return ALAC_HIP_noErr;
+}
+
+int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_ms_encode, float *out_ms_scan,
+                             float *out_ms_pack)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    ctx->profile = false;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
+    double t[3] = {0, 0, 0};
+    for (uint32_t c = 0; c < ctx->profCalls; c++)
+        for (int k = 0; k < 3; k++) {
+            float ms = 0;
+            e = hipEventElapsedTime(&ms, ctx->events[c * 4 + k], ctx->events[c * 4 + k + 1]);
+            if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime", e);
+            t[k] += ms;
+        }
+    if (out_calls) *out_calls = ctx->profCalls;
+    const double n = ctx->profCalls ? ctx->profCalls : 1;
+    if (out_ms_encode) *out_ms_encode = (float)(t[0] / n);
+    if (out_ms_scan) *out_ms_scan = (float)(t[1] / n);
+    if (out_ms_pack) *out_ms_pack = (float)(t[2] / n);
     return ALAC_HIP_noErr;
 }
 

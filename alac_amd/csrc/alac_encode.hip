@@ -545,29 +545,33 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
 
 template <int DEPTH>
 static void launch_encode_depth(const EncodeArgs &ea, const PackArgs &pa, uint32_t channels,
-                                uint32_t numPackets, hipStream_t st)
+                                uint32_t numPackets, hipStream_t st, hipEvent_t *ev)
 {
+    if (ev) (void)hipEventRecord(ev[0], st);
     if (channels == 2) {
         const uint32_t lanes = ea.numSegments * 2;
         hipLaunchKernelGGL(k_encode_stereo<DEPTH>, dim3((lanes + 63) / 64), dim3(64), 0, st, ea);
     } else {
         hipLaunchKernelGGL(k_encode_mono<DEPTH>, dim3((ea.numSegments + 63) / 64), dim3(64), 0, st, ea);
     }
+    if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const uint32_t *)ea.packetBytes, (uint64_t *)pa.offsets, numPackets);
+    if (ev) (void)hipEventRecord(ev[2], st);
     if (channels == 2)
         hipLaunchKernelGGL((k_pack<DEPTH, 2>), dim3(numPackets), dim3(256), 0, st, pa);
     else
         hipLaunchKernelGGL((k_pack<DEPTH, 1>), dim3(numPackets), dim3(256), 0, st, pa);
+    if (ev) (void)hipEventRecord(ev[3], st);
 }
 
 hipError_t launch_encode(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
-                         uint32_t numPackets, hipStream_t st)
+                         uint32_t numPackets, hipStream_t st, hipEvent_t *ev)
 {
     switch (depth) {
-    case 16: launch_encode_depth<16>(ea, pa, channels, numPackets, st); break;
-    case 20: launch_encode_depth<20>(ea, pa, channels, numPackets, st); break;
-    case 24: launch_encode_depth<24>(ea, pa, channels, numPackets, st); break;
-    case 32: launch_encode_depth<32>(ea, pa, channels, numPackets, st); break;
+    case 16: launch_encode_depth<16>(ea, pa, channels, numPackets, st, ev); break;
+    case 20: launch_encode_depth<20>(ea, pa, channels, numPackets, st, ev); break;
+    case 24: launch_encode_depth<24>(ea, pa, channels, numPackets, st, ev); break;
+    case 32: launch_encode_depth<32>(ea, pa, channels, numPackets, st, ev); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

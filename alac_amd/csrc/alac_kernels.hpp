@@ -49,8 +49,9 @@ struct PackArgs {
     uint8_t *out;
 };
 
+// ev (nullable): 4 events recorded before encode / after encode / after scan / after pack
 hipError_t launch_encode(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
-                         uint32_t numPackets, hipStream_t st);
+                         uint32_t numPackets, hipStream_t st, hipEvent_t *ev);
 
 // ---- decode ----
 struct DecChan {

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: batch ALAC encode of synthetic 44.1 kHz / 16-bit stereo packets.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the encode hot path (predictor/entropy kernel + size scan + packer) over one
+batch of synthetic packets already resident in HBM (BASELINE.json configs[1]: 10 000 independent
+4096-sample 16-bit stereo packets per GPU).  With N > 1 every rank encodes its own shard of the
+stream (frame indices rank*B .. rank*B+B-1, weak scaling) and the shard bitstreams are re-assembled
+on every rank with RCCL (all-gather of shard sizes, padded all-gather of shard bytes) — the one real
+exchange step of the path.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import alac_amd  # noqa: E402
+from alac_amd.reassemble import reassemble_shards  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(fmt, pcm_host, packets, gpu_stream=None, gpu_sizes=None):
+    """Time the CPU oracle (single thread, 'port') on a bounded sample of the same workload and, as a
+    by-product, check the GPU bytes of that sample against it."""
+    from oracle_lib import Oracle
+    o = Oracle()
+    enc = o.encoder(fmt.frame_size, fmt.bit_depth, fmt.num_channels, fmt.sample_rate)
+    nbytes = packets * fmt.packet_bytes
+    t0 = time.perf_counter()
+    ref, ref_sizes = enc.encode_stream(pcm_host[:nbytes], packets * fmt.frame_size, segment_packets=1)
+    dt = time.perf_counter() - t0
+    exact = None
+    if gpu_stream is not None:
+        n = int(ref_sizes.astype(np.int64).sum())
+        exact = bool(np.array_equal(gpu_sizes[:packets], ref_sizes) and np.array_equal(gpu_stream[:n], ref))
+    return dict(value=packets * fmt.frame_size / dt / 1e6, unit="Msamples/s", cores=1, kind="port",
+                sample=f"first {packets} packets of the workload, codec stages only (PCM in RAM -> packets in RAM), "
+                       f"oracle/alac_oracle.c -O2 single thread, {dt:.2f} s"), exact
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--packets", type=int, default=10000, help="packets per GPU per step (configs[1] = 10000)")
+    ap.add_argument("--bit-depth", type=int, default=16)
+    ap.add_argument("--cpu-packets", type=int, default=10000, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-reassemble", action="store_true", help="skip the RCCL re-assembly at N > 1")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    fmt = alac_amd.make_format(4096, args.bit_depth, 2, 44100)
+    B = args.packets
+    ctx = alac_amd.Context(local_rank)
+
+    # synthetic input, generated on the host once and made resident in HBM before any timing
+    pcm_host = alac_amd.synth_pcm(rank * B, B, fmt)
+    d_pcm = torch.from_numpy(pcm_host).cuda()
+    bufs = [ctx.encode_buffers(fmt, B) for _ in range(2)]
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+    gather = None
+
+    def step(i):
+        nonlocal gather
+        b = bufs[i & 1]
+        ctx.encode(fmt, d_pcm, B, bufs=b)
+        if world > 1 and not args.no_reassemble:
+            # re-assembly of step i runs on the side stream under the encode of step i+1
+            ev = torch.cuda.Event()
+            ev.record()
+            comm_stream.wait_event(ev)
+            with torch.cuda.stream(comm_stream):
+                gather = reassemble_shards(b["out"], b["offsets"][-1:], dist.group.WORLD, gather)
+            # the buffer pair is reused two steps later: make the main stream wait for this gather then
+            done = torch.cuda.Event()
+            done.record(comm_stream)
+            b["done"] = done
+        return b
+
+    def wait_reuse(i):
+        b = bufs[i & 1]
+        if "done" in b:
+            torch.cuda.current_stream().wait_event(b["done"])
+
+    for i in range(args.warmup):
+        wait_reuse(i)
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ctx.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wait_reuse(i)
+        last = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    calls, ms_enc, ms_scan, ms_pack = ctx.profile_end()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    total_bytes = int(last["offsets"][-1].item())
+    if rank == 0:
+        samples = world * B * fmt.frame_size * args.steps
+        value = samples / dt / 1e6
+        # dominant kernel = the fused mix + predictor + entropy kernel.  Algorithmic bytes per launch
+        # (fused design): PCM in + emitted packet bytes, per packet, x packets per launch.
+        algo_bytes = B * fmt.packet_bytes + total_bytes
+        achieved = algo_bytes / (ms_enc * 1e-3) / 1e9 if ms_enc > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                key = f"{args.bit_depth}bit_stereo_{B}"
+                traffic = tj.get(key, {}).get("encode_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "encode Msamples/s (bit-exact) 44.1kHz/16-bit stereo",
+            "value": round(value, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32" if args.bit_depth != 16 else "int32 (int16 PCM, int16 coefficients)",
+            "data": "synthetic",
+            "config": {"workload": f"{B} independent 4096-sample {args.bit_depth}-bit stereo packets per GPU "
+                                   "(BASELINE.json configs[1]), 8 deterministic signal classes, inputs resident in HBM",
+                       "packets_per_gpu": B, "frame_size": 4096, "bit_depth": args.bit_depth, "channels": 2,
+                       "segments": "one packet per segment (state = init_coefs)",
+                       "reassembly": ("none (1 GPU)" if world == 1 else
+                                      ("skipped" if args.no_reassemble else "RCCL all-gather of shard bitstreams, "
+                                       "overlapped with the next step's encode"))},
+            "packets_per_s": round(world * B * args.steps / dt, 1),
+            "x_realtime": round(value * 1e6 / 44100.0, 1),
+            "output_bytes_per_step_per_gpu": total_bytes,
+            "kernel_ms": {"encode": round(ms_enc, 4), "scan": round(ms_scan, 4), "pack": round(ms_pack, 4),
+                          "calls_timed": calls},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_encode_stereo", "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "latency-bound by the serial sign-LMS / Golomb recurrences, not by HBM"},
+        }
+        if world == 1 and args.cpu_packets > 0:
+            n = min(args.cpu_packets, B)
+            g_stream = last["out"][:total_bytes].cpu().numpy()
+            g_sizes = last["sizes"].cpu().numpy().astype(np.uint32)
+            base, exact = cpu_baseline(fmt, pcm_host, n, g_stream, g_sizes)
+            out["cpu_baseline"] = base
+            out["bit_exact_vs_cpu"] = exact
+            out["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

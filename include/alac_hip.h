@@ -92,6 +92,14 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
                         uint8_t *d_out, uint64_t out_capacity, uint32_t *d_packet_bytes,
                         uint64_t *d_packet_offsets);
 
+/* Per-kernel timing with HIP events recorded on the context's stream around the three kernels of
+ * alac_hip_encode (the instrumented counterpart of the dead cudaEvent timing in
+ * codec/CudaAlacEncoder.cu:52-65).  begin() arms up to max_calls encode calls; end() synchronises and
+ * returns the number of calls timed and the mean milliseconds of the encode, scan and pack kernels. */
+int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls);
+int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_ms_encode,
+                             float *out_ms_scan, float *out_ms_pack);
+
 /* 24-byte magic cookie (ALACSpecificConfig, big-endian): GetConfig/GetMagicCookie
  * (codec/ALACEncoder.cu:1082-1140) for <= 2 channels.  Host-only, no device work. */
 uint32_t alac_hip_magic_cookie(const alac_hip_format *fmt, uint32_t max_frame_bytes,
