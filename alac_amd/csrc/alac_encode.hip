@@ -349,8 +349,11 @@ __global__ __launch_bounds__(64) void k_encode_mono(EncodeArgs A)
         for (int k = 0; k < 16; k++) {
             s[k] = (int16_t)(k < 4 ? a3[k] : 0);
             s[16 + k] = (int16_t)(k < 8 ? a7[k] : 0);
-            s[32 + k] = 0;
-            s[48 + k] = 0;
+            if (!A.stateIn) {  // V rows are never touched by a mono element: leave them as init_coefs
+                const int16_t init = (int16_t)(k == 0 ? 1216 : k == 1 ? -928 : k == 2 ? -64 : 0);
+                s[32 + k] = init;
+                s[48 + k] = init;
+            }
         }
     }
 }

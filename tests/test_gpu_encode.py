@@ -22,3 +22,122 @@ def test_independent_packets_match_oracle(gpu_ctx, oracle, depth, channels):
     ref, ref_sizes = _oracle_stream(oracle, fmt, pcm, n * 4096, 1)
     assert np.array_equal(sizes, ref_sizes)
     assert np.array_equal(stream, ref)
+
+
+SIZES = [1, 2, 7, 8, 9, 31, 32, 39, 40, 63, 64, 71, 72, 100, 255, 287, 288, 289, 404, 1904, 3544, 4095, 4096]
+
+
+@pytest.mark.parametrize("depth,channels", [(16, 2), (24, 2), (16, 1), (32, 1), (20, 2)])
+def test_partial_packets_match_oracle(gpu_ctx, oracle, depth, channels):
+    """ragged packets, incl. N/8 <= numactive and N < 8 (empty search passes)"""
+    import torch
+    fmt = alac_amd.make_format(4096, depth, channels)
+    n = len(SIZES)
+    pcm = alac_amd.synth_pcm(2, n, fmt)
+    ns = torch.tensor(SIZES, dtype=torch.int32).cuda()
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, num_samples=ns)
+    enc = oracle.encoder(4096, depth, channels)
+    off = 0
+    for p, N in enumerate(SIZES):
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + N * fmt.bytes_per_frame], N)
+        assert sizes[p] == len(pk), (p, N)
+        assert np.array_equal(stream[off:off + len(pk)], pk), (p, N)
+        off += len(pk)
+    assert off == len(stream)
+
+
+@pytest.mark.parametrize("depth,channels", [(16, 2), (24, 2), (16, 1)])
+def test_chained_segments_and_state(gpu_ctx, oracle, depth, channels):
+    """segments of different lengths chained through the coefficient state; state out == oracle state;
+    a second call continuing from that state == one long chain."""
+    import torch
+    fmt = alac_amd.make_format(4096, depth, channels)
+    seg_first = [0, 1, 4, 9, 10, 17]
+    n = seg_first[-1]
+    pcm = alac_amd.synth_pcm(40, n, fmt)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    sf = torch.tensor(seg_first, dtype=torch.int32).cuda()
+    state = torch.zeros((len(seg_first) - 1, 64), dtype=torch.int16).cuda()
+    stream, sizes = gpu_ctx.encode_to_host(fmt, d_pcm, n, seg_first=sf, state=state)
+    off = 0
+    for s in range(len(seg_first) - 1):
+        a, b = seg_first[s], seg_first[s + 1]
+        enc = oracle.encoder(4096, depth, channels)
+        ref, rs = enc.encode_stream(pcm[a * fmt.packet_bytes:b * fmt.packet_bytes], (b - a) * 4096, 0)
+        assert np.array_equal(sizes[a:b], rs)
+        assert np.array_equal(stream[off:off + len(ref)], ref), s
+        assert np.array_equal(state[s].cpu().numpy(), enc.get_state()), s
+        off += len(ref)
+    # continue every segment with 2 more packets from the saved state
+    more = alac_amd.synth_pcm(80, 2 * (len(seg_first) - 1), fmt)
+    sf2 = torch.arange(0, 2 * (len(seg_first) - 1) + 1, 2, dtype=torch.int32).cuda()
+    st2 = state.clone()
+    stream2, sizes2 = gpu_ctx.encode_to_host(fmt, torch.from_numpy(more).cuda(), 2 * (len(seg_first) - 1),
+                                             seg_first=sf2, state=st2, state_in=True)
+    off = 0
+    for s in range(len(seg_first) - 1):
+        enc = oracle.encoder(4096, depth, channels)
+        enc.set_state(state[s].cpu().numpy())
+        ref, _ = enc.encode_stream(more[2 * s * fmt.packet_bytes:(2 * s + 2) * fmt.packet_bytes], 2 * 4096, 0)
+        assert np.array_equal(stream2[off:off + len(ref)], ref), s
+        off += len(ref)
+
+
+@pytest.mark.parametrize("kind,ch", [("stereo", 2), ("mono", 1)])
+def test_golden_packet_fixtures(gpu_ctx, kind, ch):
+    """excerpts of the reference's audio files; expected packets came from the reference's own stage
+    objects (tests/golden/make_golden.py)"""
+    import os
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "packets.npz"))
+    fmt = alac_amd.make_format(4096, 16, ch)
+    pcm = z[f"{kind}_pcm"]
+    total = len(pcm) // fmt.bytes_per_frame
+    n = (total + 4095) // 4096
+    padded = np.zeros(n * fmt.packet_bytes, np.uint8)
+    padded[:len(pcm)] = pcm
+    ns = torch.tensor([4096] * (n - 1) + [total - 4096 * (n - 1)], dtype=torch.int32).cuda()
+    d = torch.from_numpy(padded).cuda()
+    s, sz = gpu_ctx.encode_to_host(fmt, d, n, num_samples=ns)
+    assert np.array_equal(sz, z[f"{kind}_indep_sizes"]) and np.array_equal(s, z[f"{kind}_indep_stream"])
+    sf = torch.tensor([0, n], dtype=torch.int32).cuda()
+    s, sz = gpu_ctx.encode_to_host(fmt, d, n, num_samples=ns, seg_first=sf)
+    assert np.array_equal(sz, z[f"{kind}_chained_sizes"]) and np.array_equal(s, z[f"{kind}_chained_stream"])
+
+
+def test_full_size_properties_10k(gpu_ctx, oracle):
+    """BASELINE configs[1] at full size: size-independent properties (decode round trip, idempotence,
+    scan consistency) + oracle bytes on a sampled subset."""
+    import torch
+    fmt = alac_amd.make_format(4096, 16, 2)
+    n = 10000
+    pcm = alac_amd.synth_pcm(0, n, fmt)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    b = gpu_ctx.encode(fmt, d_pcm, n)
+    gpu_ctx.synchronize()
+    offs = b["offsets"].cpu().numpy()
+    sizes = b["sizes"].cpu().numpy().astype(np.int64)
+    assert offs[0] == 0 and np.array_equal(np.diff(offs), sizes)
+    total = int(offs[-1])
+    stream = b["out"][:total].clone()
+    b2 = gpu_ctx.encode(fmt, d_pcm, n)
+    gpu_ctx.synchronize()
+    assert torch.equal(b2["out"][:total], stream) and torch.equal(b2["sizes"], b["sizes"])
+    out, ns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), stream, b["offsets"], n)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and bool((ns == 4096).all())
+    assert torch.equal(out, d_pcm)
+    host = stream.cpu().numpy()
+    enc = oracle.encoder(4096, 16, 2)
+    for p in list(range(0, n, 101)) + [n - 1]:
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], 4096)
+        assert np.array_equal(host[offs[p]:offs[p + 1]], pk), p
+
+
+def test_rejects_bad_arguments(gpu_ctx):
+    import torch
+    fmt = alac_amd.make_format(4096, 12, 2)
+    with pytest.raises(Exception):
+        gpu_ctx.encode(fmt, torch.zeros(1 << 16, dtype=torch.uint8).cuda(), 1)

@@ -1,0 +1,252 @@
+"""CPU suite: the oracle (oracle/alac_oracle.c) against the golden vectors produced from the reference's
+own compiled stage objects, against those objects live when oracle/_ref is present, and against the
+reference algorithm's own losslessness (encode -> decode round trips, edge cases)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import alac_amd
+from oracle_lib import read_wav
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def stage():
+    z = np.load(os.path.join(GOLD, "stage_vectors.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return z, meta
+
+
+@pytest.fixture(scope="module")
+def known():
+    with open(os.path.join(GOLD, "known_answers.json")) as f:
+        return json.load(f)
+
+
+# ---- stage level vs golden vectors (SURVEY §8c pins 1 and 2) ------------------------------------
+
+def test_pc_block_golden(oracle, stage):
+    z, meta = stage
+    cases = [m for m in meta if m["kind"] == "pc"]
+    assert len(cases) >= 50
+    for m in cases:
+        i = m["id"]
+        pc, after = oracle.pc_block(z[f"pc{i}_x"], m["num"], z[f"pc{i}_coefs"], m["numactive"], m["chanbits"])
+        assert np.array_equal(pc, z[f"pc{i}_pc"]), m
+        assert np.array_equal(after, z[f"pc{i}_after"]), m
+
+
+def test_unpc_block_inverts_golden(oracle, stage):
+    z, meta = stage
+    for m in [m for m in meta if m["kind"] == "pc"]:
+        i = m["id"]
+        num = m["num"]
+        out, after = oracle.unpc_block(z[f"pc{i}_pc"], num, z[f"pc{i}_coefs"], m["numactive"], m["chanbits"])
+        x = z[f"pc{i}_x"]
+        sh = 32 - m["chanbits"]
+        want = ((x[:num].astype(np.int64) << sh).astype(np.int32) >> sh) if m["numactive"] else x[:num]
+        # the predictor is lossless for inputs that fit chanbits (all generated inputs do)
+        assert np.array_equal(out[:num], want), m
+        if m["numactive"] not in (0, 31) and num > m["numactive"]:
+            assert np.array_equal(after, z[f"pc{i}_after"]), m
+
+
+def test_dyn_comp_golden(oracle, stage):
+    z, meta = stage
+    cases = [m for m in meta if m["kind"] == "ag"]
+    assert len(cases) >= 50
+    for m in cases:
+        j = m["id"]
+        data, nbits = oracle.dyn_comp(z[f"ag{j}_pc"], m["bits"], start_bit=m["start_bit"])
+        assert nbits == m["nbits"], m
+        assert np.array_equal(data, z[f"ag{j}_bytes"]), m
+
+
+def test_dyn_decomp_inverts_golden(oracle, stage):
+    z, meta = stage
+    for m in [m for m in meta if m["kind"] == "ag"]:
+        j = m["id"]
+        data = z[f"ag{j}_bytes"]
+        st, pc, nbits = oracle.dyn_decomp(data, len(data), m["n"], m["bits"], start_bit=m["start_bit"])
+        assert st == 0 and nbits == m["nbits"], m
+        assert np.array_equal(pc, z[f"ag{j}_pc"]), m
+
+
+# ---- live against the reference objects (build container only) ----------------------------------
+
+def test_stages_match_reference_objects_randomized(oracle, ref):
+    rng = np.random.default_rng(7)
+    for trial in range(150):
+        na = int(rng.choice([0, 1, 2, 3, 4, 5, 8, 16, 30, 31]))
+        cb = int(rng.choice([16, 17, 20, 21, 24]))
+        num = int(rng.choice([0, 1, 5, 12, 128, 512, 1000]))
+        amp = int(rng.choice([3, 500, 30000, 1 << (cb - 1)]))
+        x = rng.integers(-amp, amp, size=max(num, 40) + 8).astype(np.int32)
+        co = rng.integers(-2000, 2000, size=32).astype(np.int16)
+        a, ca = oracle.pc_block(x, num, co, na, cb)
+        b, cb2 = oracle.pc_block(x, num, co, na, cb, fn=ref.lib.pc_block)
+        assert np.array_equal(a, b) and np.array_equal(ca, cb2)
+        y, cy = oracle.unpc_block(a, num, co, na, cb)
+        y2, cy2 = oracle.unpc_block(a, num, co, na, cb, fn=ref.lib.unpc_block)
+        assert np.array_equal(y, y2) and np.array_equal(cy, cy2)
+        bs = int(rng.choice([16, 17, 20, 21, 24, 32]))
+        n = int(rng.choice([0, 1, 7, 128, 512]))
+        lim = (1 << (bs - 1)) - 1
+        pc = np.clip((rng.standard_normal(n) * rng.choice([2, 300, lim])).astype(np.int64), -lim, lim).astype(np.int32)
+        d1, n1 = oracle.dyn_comp(pc, bs, start_bit=trial % 8)
+        d2, n2 = oracle.dyn_comp(pc, bs, start_bit=trial % 8, fn=ref.lib.ref_dyn_comp_flat)
+        assert n1 == n2 and np.array_equal(d1, d2)
+        st, back, n3 = oracle.dyn_decomp(d1, len(d1), n, bs, start_bit=trial % 8, fn=ref.lib.ref_dyn_decomp_flat)
+        assert st == 0 and n3 == n1 and np.array_equal(back, pc)
+
+
+def test_bit_writer_matches_reference(oracle, ref):
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    a = np.full(64, 0xA5, np.uint8)
+    b = a.copy()
+    pa, pb = C.c_uint64(3), C.c_uint64(3)
+    for _ in range(40):
+        nb = int(rng.integers(1, 33))
+        v = int(rng.integers(0, 1 << 32))
+        if pa.value + nb > 60 * 8:
+            break
+        oracle.lib.oalac_put_bits(a.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(pa), v, nb)
+        ref.lib.ref_put_bits(b.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(pb), v, nb)
+        assert pa.value == pb.value
+    assert np.array_equal(a, b)
+
+
+def test_driver_same_bytes_over_reference_stages(oracle, ref):
+    """EncodeStereo/EncodeMono restatement driving the reference's pc_block/dyn_comp == driving the
+    oracle's own stage functions; decode through the reference's dyn_decomp/unpc_block round-trips."""
+    H = ref.hooks()
+    for depth, ch in ((16, 2), (24, 2), (20, 1), (32, 2)):
+        fmt = alac_amd.make_format(4096, depth, ch)
+        pcm = alac_amd.synth_pcm(0, 16, fmt)
+        total = 16 * 4096 - 777
+        s_own, z_own = oracle.encoder(4096, depth, ch).encode_stream(pcm, total, 0)
+        s_ref, z_ref = oracle.encoder(4096, depth, ch, hooks=H).encode_stream(pcm, total, 0)
+        assert np.array_equal(z_own, z_ref) and np.array_equal(s_own, s_ref)
+        enc = oracle.encoder(4096, depth, ch)
+        dec = oracle.decoder(enc.cookie(), hooks=H)
+        off = 0
+        back = []
+        for z in z_own:
+            st, p, n = dec.decode_packet(s_own[off:off + z], fmt.bytes_per_frame)
+            assert st == 0
+            back.append(p)
+            off += int(z)
+        assert np.array_equal(np.concatenate(back), pcm[:total * fmt.bytes_per_frame])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/audio"), reason="reference audio not present")
+def test_reference_wav_known_answers(oracle, known):
+    for name, ka in known["wav"].items():
+        ch, rate, bits, data = read_wav(os.path.join("/root/reference/audio", name))
+        assert (ch, bits, rate) == (ka["channels"], ka["bits"], ka["rate"])
+        total = len(data) // (ch * bits // 8)
+        assert total == ka["sample_frames"]
+        s, sz = oracle.encoder(4096, bits, ch, rate).encode_stream(data, total, 0)
+        assert len(sz) == ka["packets"] and len(s) == ka["chained_bytes"]
+        assert f"{oracle.fnv(s):016x}" == ka["chained_fnv"]
+        assert [int(x) for x in sz[:8]] == ka["chained_first_sizes"] and int(sz[-1]) == ka["chained_last_size"]
+
+
+def test_survey_known_answers(known):
+    """Values recorded independently in SURVEY.md §8c by the survey's own probe of the reference objects."""
+    assert known["wav"]["50.wav"]["chained_bytes"] == 1164578 and known["wav"]["50.wav"]["packets"] == 237
+    assert known["wav"]["50.wav"]["indep_bytes"] == 1180470
+    assert known["wav"]["70.wav"]["chained_bytes"] == 7268 and known["wav"]["70.wav"]["packets"] == 227
+    assert known["wav"]["05.wav"]["chained_bytes"] == 513548 and known["wav"]["05.wav"]["packets"] == 302
+    assert known["wav"]["50.wav"]["chained_first_sizes"][6:8] == [7878, 6041]
+    assert known["silent_stereo_packet"] == ("200000040013080981f8c1ff80000013080981f8c1ff800000ff87ffbfe1fffc")
+    assert known["silent_mono_packet"] == "000000000013080981f8c1ff800000ff87fff0"
+    assert known["cookie_16bit_stereo_44k1"] == "000010000010280a0e0200ff00000000000000000000ac44"
+
+
+# ---- packet level vs golden fixtures --------------------------------------------------------------
+
+@pytest.mark.parametrize("kind,ch", [("stereo", 2), ("mono", 1)])
+def test_packet_fixtures(oracle, kind, ch):
+    z = np.load(os.path.join(GOLD, "packets.npz"))
+    pcm = z[f"{kind}_pcm"]
+    total = len(pcm) // (2 * ch)
+    for mode, seg in (("chained", 0), ("indep", 1)):
+        s, sz = oracle.encoder(4096, 16, ch).encode_stream(pcm, total, seg)
+        assert np.array_equal(sz, z[f"{kind}_{mode}_sizes"])
+        assert np.array_equal(s, z[f"{kind}_{mode}_stream"])
+
+
+def test_synthetic_known_answers(oracle, known):
+    for key, ka in known["synthetic"].items():
+        depth, ch = int(key.split("bit_")[0]), int(key.split("_")[1][0])
+        fmt = alac_amd.make_format(4096, depth, ch)
+        pcm = alac_amd.synth_pcm(0, ka["frames"], fmt)
+        assert f"{oracle.fnv(pcm):016x}" == ka["pcm_fnv"], "synthetic generator changed"
+        s, sz = oracle.encoder(4096, depth, ch).encode_stream(pcm, ka["frames"] * 4096, 1)
+        assert [int(x) for x in sz] == ka["sizes"]
+        assert f"{oracle.fnv(s):016x}" == ka["fnv"]
+
+
+def test_silent_packet_and_cookie(oracle, known):
+    e = oracle.encoder(4096, 16, 2)
+    # alacconvert fetches the cookie before encoding (convert-utility/main.cu:424-426): stats are 0
+    assert e.cookie().tobytes().hex() == known["cookie_16bit_stereo_44k1"]
+    assert e.encode_packet(np.zeros(16384, np.uint8), 4096).tobytes().hex() == known["silent_stereo_packet"]
+    assert e.cookie()[12:16].tobytes().hex() == "00000020"  # maxFrameBytes after one 32-byte packet
+    e = oracle.encoder(4096, 16, 1)
+    assert e.encode_packet(np.zeros(8192, np.uint8), 4096).tobytes().hex() == known["silent_mono_packet"]
+
+
+# ---- losslessness and edge cases -------------------------------------------------------------------
+
+@pytest.mark.parametrize("depth", [16, 20, 24, 32])
+@pytest.mark.parametrize("ch", [1, 2])
+def test_round_trip_all_partial_sizes(oracle, depth, ch):
+    """empty / ragged packets: every N in a sweep, incl. the N/8 < numactive and N < 8 corners."""
+    fmt = alac_amd.make_format(4096, depth, ch)
+    pcm = alac_amd.synth_pcm(0, 8, fmt)
+    enc = oracle.encoder(4096, depth, ch)
+    dec = oracle.decoder(enc.cookie())
+    sizes = [1, 2, 7, 8, 9, 31, 32, 39, 40, 63, 64, 71, 72, 100, 255, 287, 288, 289, 404, 1904, 3544, 4095, 4096]
+    for i, n in enumerate(sizes):
+        f = i % 8
+        src = pcm[f * fmt.packet_bytes:f * fmt.packet_bytes + n * fmt.bytes_per_frame]
+        pk = enc.encode_packet(src, n)
+        st, out, ns = dec.decode_packet(pk, fmt.bytes_per_frame)
+        assert st == 0 and ns == n
+        assert np.array_equal(out, src), (depth, ch, n)
+
+
+def test_escape_packets(oracle):
+    fmt = alac_amd.make_format(4096, 16, 2)
+    pcm = alac_amd.synth_pcm(1, 1, fmt)  # class 1 = full-scale white noise
+    enc = oracle.encoder(4096, 16, 2)
+    pk = enc.encode_packet(pcm, 4096)
+    assert enc.last_info()["escape"] == 1 and len(pk) == 16388
+    pk = enc.encode_packet(pcm[:4 * 1000], 1000)  # partial escape adds the 32-bit length
+    assert enc.last_info()["escape"] == 1 and len(pk) == (7 + 16 + 32 + 1000 * 32 + 3 + 7) // 8
+
+
+def test_decoder_rejects_garbage(oracle):
+    enc = oracle.encoder(4096, 16, 2)
+    dec = oracle.decoder(enc.cookie())
+    st, _, _ = dec.decode_packet(np.array([0x20, 0x10, 0, 0], np.uint8), 4)  # non-zero unused header bits
+    assert st == -50
+    assert oracle.decoder(np.zeros(8, np.uint8)).h is None
+
+
+def test_state_carry_equals_chained(oracle):
+    fmt = alac_amd.make_format(4096, 16, 2)
+    pcm = alac_amd.synth_pcm(16, 6, fmt)
+    whole, sizes = oracle.encoder(4096, 16, 2).encode_stream(pcm, 6 * 4096, 0)
+    e1 = oracle.encoder(4096, 16, 2)
+    a, _ = e1.encode_stream(pcm[:3 * fmt.packet_bytes], 3 * 4096, 0)
+    e2 = oracle.encoder(4096, 16, 2)
+    e2.set_state(e1.get_state())
+    b, _ = e2.encode_stream(pcm[3 * fmt.packet_bytes:], 3 * 4096, 0)
+    assert np.array_equal(np.concatenate([a, b]), whole)

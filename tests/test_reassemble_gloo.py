@@ -1,0 +1,58 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py (shard -> encode -> re-assemble) gives the
+same stream as one process encoding everything.  Shards are encoded with the CPU oracle here; on the
+GPU node the same reassemble_shards() runs over RCCL."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, per_rank, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import alac_amd
+    from alac_amd.reassemble import reassemble_shards
+    from oracle_lib import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fmt = alac_amd.make_format(4096, 16, 2)
+    pcm = alac_amd.synth_pcm(rank * per_rank, per_rank, fmt)
+    s, sizes = Oracle().encoder(4096, 16, 2).encode_stream(pcm, per_rank * 4096, 1)
+    cap = per_rank * 16400
+    shard = torch.zeros(cap, dtype=torch.uint8)
+    shard[:len(s)] = torch.from_numpy(s)
+    res = None
+    for _ in range(2):  # second call reuses the cached buffers
+        res = reassemble_shards(shard, torch.tensor([len(s)], dtype=torch.int64), None, res)
+    q.put((rank, res["stream"][:res["total"]].numpy().copy(), res["offsets"].numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reassembly_equals_single_stream():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import alac_amd
+    from oracle_lib import Oracle
+    world, per_rank = 2, 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fmt = alac_amd.make_format(4096, 16, 2)
+    pcm = alac_amd.synth_pcm(0, world * per_rank, fmt)
+    want, sizes = Oracle().encoder(4096, 16, 2).encode_stream(pcm, world * per_rank * 4096, 1)
+    for rank, stream, offsets in got:
+        assert np.array_equal(stream, want), f"rank {rank}"
+        assert offsets[-1] == len(want) and offsets[1] == int(sizes[:per_rank].sum())
