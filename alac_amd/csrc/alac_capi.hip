@@ -54,6 +54,9 @@ struct EncLayout {
     uint64_t recs, bitWords, pred, total;
     uint32_t wcap;
     uint64_t predStride;
+    // tap-parallel pipeline: residual planes [sample][stream], decision scratch, working state
+    uint64_t resA, resB, resC, bits1, cost2, state;
+    uint32_t chainsPad;
 };
 
 EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t numSegments)
@@ -71,8 +74,33 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     off = align_up(off + (uint64_t)numPackets * 2 * L.wcap * 4, 256);
     L.pred = off;
     off = align_up(off + (uint64_t)(f->frame_size / 8 + 1) * lanes * 4, 256);
+    L.chainsPad = (uint32_t)lanes;
+    const uint64_t n8 = f->frame_size / 8 + 1;
+    L.resA = off;
+    off = align_up(off + (f->num_channels == 2 ? n8 * 5 * lanes * 4 : 0), 256);
+    L.resB = off;
+    off = align_up(off + n8 * 2 * lanes * 4, 256);
+    L.resC = off;
+    off = align_up(off + (uint64_t)f->frame_size * lanes * 4, 256);
+    L.bits1 = off;
+    off = align_up(off + 5 * lanes * 4, 256);
+    L.cost2 = off;
+    off = align_up(off + 2 * lanes * 4, 256);
+    L.state = off;
+    off = align_up(off + (uint64_t)numSegments * 128, 256);
     L.total = off;
     return L;
+}
+
+// ALAC_HIP_ENCODER=lane selects the fused lane-per-chain kernel (alac_encode.hip); default is the
+// tap-parallel pipeline (alac_encode_v1.hip).  Both are HIP paths; there is no CPU path.
+bool use_lane_encoder()
+{
+    static const int v = [] {
+        const char *e = getenv("ALAC_HIP_ENCODER");
+        return (e && strcmp(e, "lane") == 0) ? 1 : 0;
+    }();
+    return v != 0;
 }
 
 struct DecLayout {
@@ -220,18 +248,56 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
     pa.frameSize = fmt->frame_size;
     pa.offsets = d_packet_offsets;
     pa.out = d_out;
+    constexpr uint32_t EV = kNumStages + 1;
     hipEvent_t *ev = nullptr;
-    if (ctx->profile && (uint64_t)(ctx->profCalls + 1) * 4 <= ctx->events.size()) ev = &ctx->events[ctx->profCalls++ * 4];
-    hipError_t e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream, ev);
+    if (ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size()) ev = &ctx->events[ctx->profCalls++ * EV];
+    hipError_t e;
+    if (use_lane_encoder()) {
+        e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream, ev);
+    } else {
+        // packets per segment: the pipeline runs once per packet position (a chained segment is serial)
+        uint32_t maxSeg = 1;
+        if (d_seg_first) {
+            std::vector<uint32_t> sf(num_segments + 1);
+            if (hipMemcpyAsync(sf.data(), d_seg_first, (num_segments + 1) * 4ull, hipMemcpyDeviceToHost, ctx->stream) !=
+                    hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return fail(ctx, ALAC_HIP_ParamError, "reading d_seg_first");
+            maxSeg = 0;
+            for (uint32_t s = 0; s < num_segments; s++) {
+                if (sf[s + 1] < sf[s] || sf[s + 1] > num_packets) return fail(ctx, ALAC_HIP_ParamError, "bad d_seg_first");
+                maxSeg = sf[s + 1] - sf[s] > maxSeg ? sf[s + 1] - sf[s] : maxSeg;
+            }
+        }
+        V1Buffers vb;
+        vb.state = d_state ? d_state : (int16_t *)(ws + L.state);
+        vb.stateInitialised = d_state && state_in;
+        vb.resA = (int32_t *)(ws + L.resA);
+        vb.resB = (int32_t *)(ws + L.resB);
+        vb.resC = (int32_t *)(ws + L.resC);
+        vb.bits1 = (uint32_t *)(ws + L.bits1);
+        vb.cost2 = (uint32_t *)(ws + L.cost2);
+        vb.chainsPad = L.chainsPad;
+        e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, num_packets, maxSeg, ctx->stream, ev);
+    }
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "encode launch", e);
     return ALAC_HIP_noErr;
+}
+
+uint32_t alac_hip_num_stages(void) { return kNumStages; }
+
+const char *alac_hip_stage_name(uint32_t stage)
+{
+    static const char *names[kNumStages] = {"lms_search1", "golomb_count1", "lms_search2", "golomb_count2",
+                                            "lms_final",   "golomb_final",  "finalize_scan", "pack"};
+    return stage < kNumStages ? names[stage] : "";
 }
 
 int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls)
 {
     if (!ctx) return ALAC_HIP_ParamError;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
-    while (ctx->events.size() < (size_t)max_calls * 4) {
+    while (ctx->events.size() < (size_t)max_calls * (kNumStages + 1)) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return fail(ctx, ALAC_HIP_MemFullError, "hipEventCreate");
         ctx->events.push_back(e);
@@ -241,26 +307,25 @@ int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls)
     return ALAC_HIP_noErr;
 }
 
-int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_ms_encode, float *out_ms_scan,
-                             float *out_ms_pack)
+int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_stage_ms)
 {
     if (!ctx) return ALAC_HIP_ParamError;
     ctx->profile = false;
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
-    double t[3] = {0, 0, 0};
+    constexpr uint32_t EV = kNumStages + 1;
+    double t[kNumStages] = {0};
     for (uint32_t c = 0; c < ctx->profCalls; c++)
-        for (int k = 0; k < 3; k++) {
+        for (uint32_t k = 0; k < kNumStages; k++) {
             float ms = 0;
-            e = hipEventElapsedTime(&ms, ctx->events[c * 4 + k], ctx->events[c * 4 + k + 1]);
+            e = hipEventElapsedTime(&ms, ctx->events[c * EV + k], ctx->events[c * EV + k + 1]);
             if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime", e);
             t[k] += ms;
         }
     if (out_calls) *out_calls = ctx->profCalls;
     const double n = ctx->profCalls ? ctx->profCalls : 1;
-    if (out_ms_encode) *out_ms_encode = (float)(t[0] / n);
-    if (out_ms_scan) *out_ms_scan = (float)(t[1] / n);
-    if (out_ms_pack) *out_ms_pack = (float)(t[2] / n);
+    if (out_stage_ms)
+        for (uint32_t k = 0; k < kNumStages; k++) out_stage_ms[k] = (float)(t[k] / n);
     return ALAC_HIP_noErr;
 }
 

@@ -547,24 +547,45 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
 // ------------------------------------------------------------------------------------------------
 
 template <int DEPTH>
+static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, const PackArgs &pa, uint32_t numPackets,
+                                   hipStream_t st, hipEvent_t *ev, bool recordScan = true)
+{
+    if (ev && recordScan) (void)hipEventRecord(ev[kStageScan], st);
+    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const uint32_t *)packetBytes, (uint64_t *)pa.offsets,
+                       numPackets);
+    if (ev) (void)hipEventRecord(ev[kStagePack], st);
+    if (channels == 2)
+        hipLaunchKernelGGL((k_pack<DEPTH, 2>), dim3(numPackets), dim3(256), 0, st, pa);
+    else
+        hipLaunchKernelGGL((k_pack<DEPTH, 1>), dim3(numPackets), dim3(256), 0, st, pa);
+    if (ev) (void)hipEventRecord(ev[kNumStages], st);
+}
+
+void launch_scan_pack(uint32_t depth, uint32_t channels, uint32_t *packetBytes, const PackArgs &pa, uint32_t numPackets,
+                      hipStream_t st, hipEvent_t *ev, bool recordScan)
+{
+    switch (depth) {
+    case 16: launch_scan_pack_depth<16>(channels, packetBytes, pa, numPackets, st, ev, recordScan); break;
+    case 20: launch_scan_pack_depth<20>(channels, packetBytes, pa, numPackets, st, ev, recordScan); break;
+    case 24: launch_scan_pack_depth<24>(channels, packetBytes, pa, numPackets, st, ev, recordScan); break;
+    default: launch_scan_pack_depth<32>(channels, packetBytes, pa, numPackets, st, ev, recordScan); break;
+    }
+}
+
+template <int DEPTH>
 static void launch_encode_depth(const EncodeArgs &ea, const PackArgs &pa, uint32_t channels,
                                 uint32_t numPackets, hipStream_t st, hipEvent_t *ev)
 {
-    if (ev) (void)hipEventRecord(ev[0], st);
+    if (ev)
+        for (int i = 0; i <= kStageLms3; i++) (void)hipEventRecord(ev[i], st);
     if (channels == 2) {
         const uint32_t lanes = ea.numSegments * 2;
         hipLaunchKernelGGL(k_encode_stereo<DEPTH>, dim3((lanes + 63) / 64), dim3(64), 0, st, ea);
     } else {
         hipLaunchKernelGGL(k_encode_mono<DEPTH>, dim3((ea.numSegments + 63) / 64), dim3(64), 0, st, ea);
     }
-    if (ev) (void)hipEventRecord(ev[1], st);
-    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const uint32_t *)ea.packetBytes, (uint64_t *)pa.offsets, numPackets);
-    if (ev) (void)hipEventRecord(ev[2], st);
-    if (channels == 2)
-        hipLaunchKernelGGL((k_pack<DEPTH, 2>), dim3(numPackets), dim3(256), 0, st, pa);
-    else
-        hipLaunchKernelGGL((k_pack<DEPTH, 1>), dim3(numPackets), dim3(256), 0, st, pa);
-    if (ev) (void)hipEventRecord(ev[3], st);
+    if (ev) (void)hipEventRecord(ev[kStageGol3], st);
+    launch_scan_pack_depth<DEPTH>(channels, ea.packetBytes, pa, numPackets, st, ev);
 }
 
 hipError_t launch_encode(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,

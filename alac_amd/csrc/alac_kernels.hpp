@@ -49,9 +49,38 @@ struct PackArgs {
     uint8_t *out;
 };
 
-// ev (nullable): 4 events recorded before encode / after encode / after scan / after pack
+// Stage timing: when `ev` is non-null, ev[i] is recorded BEFORE stage i and ev[kNumStages] after the
+// last one (stages that do not run in a given configuration record back-to-back events).
+enum EncodeStage {
+    kStageLms1 = 0,   // LPC+mix, mixRes search passes
+    kStageGol1,       // Golomb counts of those passes
+    kStageLms2,       // LPC+mix, numUV converge passes
+    kStageGol2,       // Golomb counts
+    kStageLms3,       // LPC+mix, final pass
+    kStageGol3,       // Golomb coder, final
+    kStageScan,       // finalize + exclusive scan of packet sizes
+    kStagePack,       // packer
+    kNumStages
+};
+
+// lane-per-chain encoder (alac_encode.hip): everything fused in one kernel (recorded as kStageLms3)
 hipError_t launch_encode(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
                          uint32_t numPackets, hipStream_t st, hipEvent_t *ev);
+// finalize is the caller's; this launches the size scan and the packer (records ev[kStageScan..])
+void launch_scan_pack(uint32_t depth, uint32_t channels, uint32_t *packetBytes, const PackArgs &pa,
+                      uint32_t numPackets, hipStream_t st, hipEvent_t *ev, bool recordScan = true);
+
+// tap-parallel pipeline (alac_encode_v1.hip)
+struct V1Buffers {
+    int16_t *state;        // [segments][64] working coefficient rows (caller's d_state or workspace)
+    bool stateInitialised; // rows already hold the caller's initial state
+    int32_t *resA, *resB, *resC;
+    uint32_t *bits1, *cost2;
+    uint32_t chainsPad;
+};
+hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
+                            const V1Buffers &vb, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st,
+                            hipEvent_t *ev);
 
 // ---- decode ----
 struct DecChan {

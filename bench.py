@@ -124,7 +124,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    calls, ms_enc, ms_scan, ms_pack = ctx.profile_end()
+    calls, stage_ms = ctx.profile_end()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -135,10 +135,28 @@ def main():
     if rank == 0:
         samples = world * B * fmt.frame_size * args.steps
         value = samples / dt / 1e6
-        # dominant kernel = the fused mix + predictor + entropy kernel.  Algorithmic bytes per launch
-        # (fused design): PCM in + emitted packet bytes, per packet, x packets per launch.
-        algo_bytes = B * fmt.packet_bytes + total_bytes
-        achieved = algo_bytes / (ms_enc * 1e-3) / 1e9 if ms_enc > 0 else 0.0
+        # Algorithmic bytes per launch of every stage (stand-alone LPC+mix kernel =
+        # PCM in + int32 residuals out; entropy stage = residuals in + packet bits out), x packets per launch.
+        n8 = fmt.frame_size // 8
+        res_full = B * 2 * fmt.frame_size * 4
+        algo = {
+            "lms_search1": B * 2 * n8 * (fmt.bit_depth // 8 if fmt.bit_depth != 20 else 3) + B * 2 * 5 * n8 * 4,
+            "golomb_count1": B * 2 * 5 * n8 * 4,
+            "lms_search2": B * 2 * (n8 // 4) * (fmt.bit_depth // 8 if fmt.bit_depth != 20 else 3) + B * 4 * (n8 // 4) * 4,
+            "golomb_count2": B * 4 * n8 * 4,
+            "lms_final": B * fmt.packet_bytes + res_full,
+            "golomb_final": res_full + total_bytes,
+            "finalize_scan": B * (64 + 4 + 8),
+            "pack": 2 * total_bytes,
+        }
+        if os.environ.get("ALAC_HIP_ENCODER") == "lane":  # fused kernel: PCM in + packet bytes out
+            algo["lms_final"] = B * fmt.packet_bytes + total_bytes
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        ms_dom = stage_ms[dom]
+        algo_bytes = algo[dom]
+        achieved = algo_bytes / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+        stages = {k: {"ms": round(v, 4), "algo_GBps": round(algo[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None}
+                  for k, v in stage_ms.items()}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -146,7 +164,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 key = f"{args.bit_depth}bit_stereo_{B}"
-                traffic = tj.get(key, {}).get("encode_kernel_hbm_bytes_per_launch")
+                traffic = tj.get(key, {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -172,12 +190,13 @@ def main():
             "packets_per_s": round(world * B * args.steps / dt, 1),
             "x_realtime": round(value * 1e6 / 44100.0, 1),
             "output_bytes_per_step_per_gpu": total_bytes,
-            "kernel_ms": {"encode": round(ms_enc, 4), "scan": round(ms_scan, 4), "pack": round(ms_pack, 4),
-                          "calls_timed": calls},
+            "stages": stages,
+            "calls_timed": calls,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_encode_stereo", "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "latency-bound by the serial sign-LMS / Golomb recurrences, not by HBM"},
+                         "kernel": dom, "kernel_ms": round(ms_dom, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "dominant stage by measured time; the path is bound by serial integer "
+                                 "recurrences (sign-LMS, Golomb mean tracker), not by HBM"},
         }
         if world == 1 and args.cpu_packets > 0:
             n = min(args.cpu_packets, B)

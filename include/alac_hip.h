@@ -95,10 +95,12 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
 /* Per-kernel timing with HIP events recorded on the context's stream around the three kernels of
  * alac_hip_encode (the instrumented counterpart of the dead cudaEvent timing in
  * codec/CudaAlacEncoder.cu:52-65).  begin() arms up to max_calls encode calls; end() synchronises and
- * returns the number of calls timed and the mean milliseconds of the encode, scan and pack kernels. */
+ * returns the number of calls timed and the mean milliseconds of every pipeline stage. */
 int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls);
-int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_ms_encode,
-                             float *out_ms_scan, float *out_ms_pack);
+/* out_stage_ms: [alac_hip_num_stages()] mean milliseconds per pipeline stage (alac_hip_stage_name(i)) */
+int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_stage_ms);
+uint32_t alac_hip_num_stages(void);
+const char *alac_hip_stage_name(uint32_t stage);
 
 /* 24-byte magic cookie (ALACSpecificConfig, big-endian): GetConfig/GetMagicCookie
  * (codec/ALACEncoder.cu:1082-1140) for <= 2 channels.  Host-only, no device work. */
