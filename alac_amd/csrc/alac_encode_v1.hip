@@ -20,6 +20,7 @@
 #include "alac_dev.hpp"
 #include "alac_kernels.hpp"
 #include "alac_lms.hpp"
+#include "alac_golomb.hpp"
 
 namespace alacdev {
 
@@ -83,25 +84,67 @@ __device__ __forceinline__ void stage_rows(int32_t *xs, int rowU, int rowV, cons
 }
 
 // ---- one tile of predictor steps for the 8 chains of the wave --------------------------------------
-template <bool WIDE>
-__device__ __forceinline__ void run_tile(int32_t &a, const int32_t *xsRow, int32_t *resRow, const LmsLane &L, int j0,
-                                         int jEnd, uint32_t chanbits)
+// p[j] = in[j] - in[j-1-na] is the same for the 8 taps of a chain: computed once per sample here (8 lanes of
+// the slot x 16 rounds) instead of once per lane per step inside the recurrence loop.
+__device__ __forceinline__ void stage_p(const int32_t *xsRow, int32_t *pRow, int na, int k)
 {
-    // per-lane LDS cursors: x[j] lives at xsRow[kHist + j - j0]
+#pragma unroll
+    for (int i = 0; i < (kTile + 8) / 8; i++) {
+        const int idx = i * 8 + k;  // sample j0 + idx
+        pRow[idx] = xsRow[kHist + idx] - xsRow[kHist + idx - 1 - na];
+    }
+}
+
+// The LDS operands of a step (in[j-1-k], top, p) depend on nothing the recurrence produces, so the
+// operands of block i+1 (8 steps) are fetched into registers while block i computes.
+struct StepOps {
+    int32_t xk[8], tp[8], p[8];
+};
+
+__device__ __forceinline__ void load_ops(StepOps &o, const int32_t *px, const int32_t *pt, const int32_t *pp, int jb)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        o.xk[s] = px[jb + s];
+        o.tp[s] = pt[jb + s];
+        o.p[s] = pp[jb + s];
+    }
+}
+
+template <bool WIDE, bool MASKED>
+__device__ __forceinline__ void run_block(int32_t &a, const StepOps &o, const LmsLane &L, int jb, int32_t *resAt,
+                                          uint32_t chanbits)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int j = jb + s;
+        const int32_t liveMask = MASKED ? (((j >= L.jlo) & (j < L.jhi)) ? -1 : 0) : -1;
+        // the residual is identical in the 8 lanes of the group: all of them store it (same address, no VALU)
+        resAt[s] = lms8_step<WIDE, MASKED>(a, o.xk[s], o.tp[s], o.p[s], liveMask, L, chanbits);
+    }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void run_tile(int32_t &a, const int32_t *xsRow, const int32_t *pRow, int32_t *resRow,
+                                         const LmsLane &L, int j0, int jEnd, uint32_t chanbits)
+{
+    // per-lane LDS cursors: x[j] lives at xsRow[kHist + j - j0]; rows are long enough for the one-block
+    // over-read of the prefetch
     const int kk = L.k < L.na ? L.k : L.na;  // inert taps read "top" so their b is 0
     const int32_t *px = xsRow + kHist - 1 - kk - j0;
     const int32_t *pt = xsRow + kHist - 1 - L.na - j0;
-    const int32_t *pc = xsRow + kHist - j0;
+    const int32_t *pp = pRow - j0;
+    StepOps cur, nxt;
+    load_ops(cur, px, pt, pp, j0);
     for (int jb = j0; jb < jEnd; jb += 8) {
-        int32_t out = 0;
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const int j = jb + s;
-            const bool live = (j >= L.jlo) & (j < L.jhi);
-            const int32_t del = lms8_step<WIDE>(a, px[j], pt[j], pc[j], live, L, chanbits);
-            out = (L.k == s) ? del : out;
-        }
-        resRow[jb - j0 + L.k] = out;  // lane k keeps the residual of step jb + k: one 64-lane store per 8 steps
+        load_ops(nxt, px, pt, pp, jb + 8);
+        // wave-uniform: is every lane's chain live for the whole block?
+        const bool allLive = __all((jb >= L.jlo) & (jb + 8 <= L.jhi));
+        if (allLive)
+            run_block<WIDE, false>(a, cur, L, jb, resRow + (jb - j0), chanbits);
+        else
+            run_block<WIDE, true>(a, cur, L, jb, resRow + (jb - j0), chanbits);
+        cur = nxt;
     }
 }
 
@@ -118,9 +161,13 @@ __device__ __forceinline__ void warmup_fix(const int32_t *xsRow, int32_t *resRow
 __device__ __forceinline__ void flush_tile(const int32_t *resRow, int32_t *dst, uint64_t streamStride, uint32_t stream,
                                            int j0, uint32_t P, int k)
 {
-    for (int i = 0; i < kTile; i += 8) {
-        const uint32_t j = (uint32_t)(j0 + i + k);
-        if (j < P) dst[(uint64_t)j * streamStride + stream] = resRow[i + k];
+    int32_t v[kTile / 8];
+#pragma unroll
+    for (int i = 0; i < kTile / 8; i++) v[i] = resRow[i * 8 + k];
+#pragma unroll
+    for (int i = 0; i < kTile / 8; i++) {
+        const uint32_t j = (uint32_t)(j0 + i * 8 + k);
+        if (j < P) dst[(uint64_t)j * streamStride + stream] = v[i];
     }
 }
 
@@ -146,6 +193,7 @@ template <int DEPTH>
 __global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
 {
     __shared__ int32_t xs[8 * kXsStride];
+    __shared__ int32_t ps[8 * kResStride];
     __shared__ int32_t res[8 * kResStride];
     const int lane = threadIdx.x;
     const int g = lane >> 3, q = g >> 1, c = g & 1;
@@ -173,8 +221,10 @@ __global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
                 stage_rows<DEPTH, 2>(xs, 2 * qq, 2 * qq + 1, A.S.pcm + (uint64_t)pq * frameBytes, Nq, r, j0, lane);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            stage_p(xs + g * kXsStride, ps + g * kResStride, L.na, L.k);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             const int jEnd = min(j0 + kTile, (int)((maxn8 + 7) & ~7u));
-            run_tile<WIDE>(a, xs + g * kXsStride, res + g * kResStride, L, j0, jEnd, chanBits);
+            run_tile<WIDE>(a, xs + g * kXsStride, ps + g * kResStride, res + g * kResStride, L, j0, jEnd, chanBits);
             if (j0 == 0) warmup_fix(xs + g * kXsStride, res + g * kResStride, L, 32 - chanBits);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             if (active)
@@ -192,6 +242,7 @@ template <int DEPTH, int CH>
 __global__ __launch_bounds__(64) void k_lms_search2(V1Args A)
 {
     __shared__ int32_t xs[4 * kXsStride];
+    __shared__ int32_t ps[8 * kResStride];
     __shared__ int32_t res[8 * kResStride];
     const int lane = threadIdx.x;
     const int g = lane >> 3;
@@ -252,8 +303,10 @@ __global__ __launch_bounds__(64) void k_lms_search2(V1Args A)
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            stage_p(xs + xrow * kXsStride, ps + g * kResStride, L.na, L.k);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
-            run_tile<WIDE>(a, xs + xrow * kXsStride, res + g * kResStride, L, j0, jEnd, chanBits);
+            run_tile<WIDE>(a, xs + xrow * kXsStride, ps + g * kResStride, res + g * kResStride, L, j0, jEnd, chanBits);
             if (last) {
                 if (j0 == 0) warmup_fix(xs + xrow * kXsStride, res + g * kResStride, L, 32 - chanBits);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -273,6 +326,7 @@ template <int DEPTH, int CH>
 __global__ __launch_bounds__(64) void k_lms_final(V1Args A)
 {
     __shared__ int32_t xs[8 * kXsStride];
+    __shared__ int32_t ps[8 * kResStride];
     __shared__ int32_t res[8 * kResStride];
     const int lane = threadIdx.x;
     const int g = lane >> 3;
@@ -314,8 +368,10 @@ __global__ __launch_bounds__(64) void k_lms_final(V1Args A)
                 stage_rows<DEPTH, 1>(xs, xr, xr, pk, Nq, 0, j0, lane);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        stage_p(xs + g * kXsStride, ps + g * kResStride, L.na, L.k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         const int jEnd = min(j0 + kTile, (int)((maxN + 7) & ~7u));
-        run_tile<WIDE>(a, xs + g * kXsStride, res + g * kResStride, L, j0, jEnd, chanBits);
+        run_tile<WIDE>(a, xs + g * kXsStride, ps + g * kResStride, res + g * kResStride, L, j0, jEnd, chanBits);
         if (j0 == 0) warmup_fix(xs + g * kXsStride, res + g * kResStride, L, 32 - chanBits);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         if (active) flush_tile(res + g * kResStride, A.resC, A.chainsPad, chain, j0, N, L.k);
@@ -332,18 +388,20 @@ __global__ __launch_bounds__(64) void k_lms_final(V1Args A)
 template <int CH>
 __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
 {
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     const uint32_t chain = t % A.chainsPad, r = t / A.chainsPad;
-    if (r > (uint32_t)kMaxRes) return;
     uint32_t p, N;
-    if (!seg_packet(A.S, chain / CH, p, N)) return;
-    const uint32_t n8 = N / 8;
+    const bool active = (r <= (uint32_t)kMaxRes) && seg_packet(A.S, chain / CH, p, N);
+    const uint32_t n8 = active ? N / 8 : 0;
     const int32_t *src = A.resA + (uint64_t)r * A.chainsPad + chain;
     const uint64_t stride = 5ull * A.chainsPad;
-    Golomb g;
-    gol_reset(g, kMB0, kPB0, kKB0);
-    for (uint32_t j = 0; j < n8; j++) gol_sym<false>(g, src[j * stride], j + 1 == n8, chanBits);
-    A.bits1[t] = g.bits;
+    GolF g;
+    golf_reset(g);
+    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return src[j * stride]; });
+    if (active) A.bits1[t] = g.bits;
 }
 
 // codec/ALACEncoder.cu:374-380: first minimum of bits1 + bits2 over mixRes 0..4
@@ -368,12 +426,14 @@ __global__ void k_decide1(V1Args A)
 template <int CH>
 __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
 {
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
     const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     const uint32_t chain = t % A.chainsPad, rs = t / A.chainsPad;
-    if (rs > 1) return;
     uint32_t p, N;
-    if (!seg_packet(A.S, chain / CH, p, N)) return;
-    const uint32_t n8 = N / 8, n32 = N / 32, na = rs ? 8 : 4;
+    const bool active = (rs <= 1) && seg_packet(A.S, chain / CH, p, N);
+    const uint32_t n8 = active ? N / 8 : 0, n32 = N / 32, na = rs ? 8 : 4;
     uint32_t P2 = n8;
     if (CH == 2) {
         P2 = n32 > na + 1 ? n32 : na + 1;
@@ -383,13 +443,11 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
     const uint64_t strideB = 2ull * A.chainsPad;
     const int32_t *srcA = A.resA + (uint64_t)kMaxRes * A.chainsPad + chain;
     const uint64_t strideA = 5ull * A.chainsPad;
-    Golomb g;
-    gol_reset(g, kMB0, kPB0, kKB0);
-    for (uint32_t j = 0; j < n8; j++) {
-        const int32_t del = j < P2 ? srcB[j * strideB] : srcA[j * strideA];
-        gol_sym<false>(g, del, j + 1 == n8, chanBits);
-    }
-    A.cost2[t] = g.bits * 8 + 16 * na;  // :438, :447 / :899
+    GolF g;
+    golf_reset(g);
+    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip,
+                       [&](uint32_t j) { return j < P2 ? srcB[j * strideB] : srcA[j * strideA]; });
+    if (active) A.cost2[t] = g.bits * 8 + 16 * na;  // :438, :447 / :899
 }
 
 // numU / numV, escape estimate (codec/ALACEncoder.cu:438-461, mono :899-915), header coefficients
@@ -428,20 +486,25 @@ __global__ void k_decide2(V1Args A)
 template <int CH>
 __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
 {
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
     const uint32_t chain = blockIdx.x * 64u + threadIdx.x;
     uint32_t p, N;
-    if (!seg_packet(A.S, chain / CH, p, N)) return;
+    bool active = seg_packet(A.S, chain / CH, p, N);
     PacketRec *rec = A.recs + p;
-    if (rec->escape) return;
+    if (active && rec->escape) active = false;
     const uint32_t c = chain % CH;
+    const uint32_t n = active ? N : 0;
     const int32_t *src = A.resC + chain;
-    Golomb g;
-    gol_reset(g, kMB0, kPB0, kKB0);
+    const uint64_t stride = A.chainsPad;
+    GolF g;
+    golf_reset(g);
     g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
     g.wcap = A.wcap;
-    for (uint32_t j = 0; j < N; j++) gol_sym<true>(g, src[(uint64_t)j * A.chainsPad], j + 1 == N, chanBits);
-    gol_flush<true>(g);
-    rec->c[c].bits = g.bits;
+    golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return src[j * stride]; });
+    golf_flush<true>(g);
+    if (active) rec->c[c].bits = g.bits;
 }
 
 // packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)

@@ -84,12 +84,20 @@ __device__ __forceinline__ LmsLane make_lane(int lane, int na, int num)
 // One predictor step of all 8 chains of the wave.
 //   a    this lane's coefficient (int16 value kept in an int32)
 //   xk   in[j-1-k]  (taps k >= na are handed in[j-1-na] so that b = 0)
-//   tp   in[j-1-na] ("top"),  cu = in[j]
+//   tp   in[j-1-na] ("top"),  p = in[j] - top (same for the 8 taps: computed once per sample at staging)
 // Returns the residual (identical in the 8 lanes of a group).
 //   sum1 = (denhalf - sum) >> 9 and del = in[j] - top - sum1 (dp_enc.c:136-139) are folded into
 //   del = (in[j] - top) + ((sum + 255) >> 9): -floor((256 - s)/512) == floor((s + 255)/512).
-template <bool WIDE>
-__device__ __forceinline__ int32_t lms8_step(int32_t &a, int32_t xk, int32_t tp, int32_t cu, bool live,
+// sign(x) as clamp(x, -1, 1) in one v_med3_i32 with inline constants
+__device__ __forceinline__ int32_t sign3(int32_t x)
+{
+    int32_t r;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+template <bool WIDE, bool MASKED>
+__device__ __forceinline__ int32_t lms8_step(int32_t &a, int32_t xk, int32_t tp, int32_t p, int32_t liveMask,
                                              const LmsLane &L, uint32_t chanbits)
 {
     // ---- data-only part (off the dependent chain) ----
@@ -108,14 +116,14 @@ __device__ __forceinline__ int32_t lms8_step(int32_t &a, int32_t xk, int32_t tp,
         hi = (int32_t)group_suffix_excl8(__umul24(tpos, (uint32_t)L.wk), L.modd, L.mk1);
         lo = -(int32_t)group_suffix_excl8(__umul24(tneg, (uint32_t)L.wk), L.modd, L.mk1);
     }
-    const int32_t sb = live ? med3_i32(b, -1, 1) : 0;
-    const int32_t p = cu - tp;
+    int32_t sb = sign3(b);
+    if constexpr (MASKED) sb &= liveMask;  // steps outside [jlo, jhi) leave the coefficients alone
 
     // ---- dependent chain ----
     const int32_t s = group_sum8(__mul24((int32_t)(int16_t)a, b) + L.c255);
     const int32_t del = __builtin_amdgcn_sbfe(p + (s >> kDenShift), 0, chanbits);
     const int32_t e = med3_i32(del, lo, hi) - del;  // < 0: del > S+ (positive side), > 0: del < -S-
-    a = __mul24(med3_i32(e, -1, 1), sb) + a;        // a -= sign(del) * sign(b) on the touched taps
+    a = __mul24(sign3(e), sb) + a;                  // a -= sign(del) * sign(b) on the touched taps
     return del;
 }
 
