@@ -49,7 +49,7 @@ SIGNATURES = {
     "alac_hip_encode": (_i32, [_vp, C.POINTER(Format), _vp, _vp, _u32, _vp, _u32, _vp, _i32, _vp, _u64,
                                _vp, _u64, _vp, _vp]),
     "alac_hip_profile_begin": (_i32, [_vp, _u32]),
-    "alac_hip_profile_end": (_i32, [_vp, C.POINTER(_u32), C.POINTER(C.c_float)]),
+    "alac_hip_profile_end": (_i32, [_vp, C.POINTER(_u32), C.POINTER(C.c_float), C.POINTER(_u32)]),
     "alac_hip_num_stages": (_u32, []),
     "alac_hip_stage_name": (C.c_char_p, [_u32]),
     "alac_hip_magic_cookie": (_u32, [C.POINTER(Format), _u32, _u32, _vp]),
@@ -193,12 +193,13 @@ class Context:
         self._check(self.lib.alac_hip_profile_begin(self.h, max_calls))
 
     def profile_end(self):
-        """-> (calls, {stage name: mean ms}); synchronises."""
+        """-> (calls, {stage name: (mean ms per launch, launches per call)}); synchronises."""
         n = _u32(0)
         ns = self.lib.alac_hip_num_stages()
         ms = (C.c_float * ns)()
-        self._check(self.lib.alac_hip_profile_end(self.h, C.byref(n), ms))
-        return n.value, {self.lib.alac_hip_stage_name(i).decode(): float(ms[i]) for i in range(ns)}
+        ln = (_u32 * ns)()
+        self._check(self.lib.alac_hip_profile_end(self.h, C.byref(n), ms, ln))
+        return n.value, {self.lib.alac_hip_stage_name(i).decode(): (float(ms[i]), int(ln[i])) for i in range(ns)}
 
     def magic_cookie(self, fmt, max_frame_bytes=0, avg_bit_rate=0):
         c = np.zeros(24, np.uint8)

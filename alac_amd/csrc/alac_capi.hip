@@ -6,6 +6,7 @@
 #include "alac_kernels.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -23,6 +24,10 @@ struct alac_hip_ctx {
     bool profile = false;
     std::vector<hipEvent_t> events;
     uint32_t profCalls = 0;
+    std::vector<uint32_t> profSub;  // sub-batches used by each timed call (0 = fused lane encoder)
+    // side streams / events of the sub-batch overlap (created on first use)
+    V1Streams vs{};
+    bool vsReady = false;
 };
 
 namespace {
@@ -94,6 +99,19 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
 
 // ALAC_HIP_ENCODER=lane selects the fused lane-per-chain kernel (alac_encode.hip); default is the
 // tap-parallel pipeline (alac_encode_v1.hip).  Both are HIP paths; there is no CPU path.
+// ALAC_HIP_SUBBATCH=n (1..8) overrides the number of overlapped sub-batches of the tap-parallel pipeline
+uint32_t sub_batches_requested()
+{
+    static const uint32_t v = [] {
+        const char *e = getenv("ALAC_HIP_SUBBATCH");
+        int n = e ? atoi(e) : 1;  // measured: no gain at 10k packets, every kernel is bound by one wave's latency
+        if (n < 1) n = 1;
+        if (n > (int)kMaxSubBatches) n = kMaxSubBatches;
+        return (uint32_t)n;
+    }();
+    return v;
+}
+
 bool use_lane_encoder()
 {
     static const int v = [] {
@@ -170,6 +188,16 @@ void alac_hip_destroy(alac_hip_ctx *ctx)
     if (!ctx) return;
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
     ctx->events.clear();
+    if (ctx->vsReady) {
+        (void)hipSetDevice(ctx->device);
+        for (uint32_t i = 0; i + 1 < kMaxSubBatches; i++) {
+            (void)hipStreamSynchronize(ctx->vs.side[i]);
+            (void)hipStreamDestroy(ctx->vs.side[i]);
+            (void)hipEventDestroy(ctx->vs.stagger[i]);
+            (void)hipEventDestroy(ctx->vs.join[i]);
+        }
+        (void)hipEventDestroy(ctx->vs.fork);
+    }
     if (ctx->ownStream && ctx->stream) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -217,8 +245,8 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
         return fail(ctx, ALAC_HIP_ParamError, "null buffer");
     if (!d_seg_first) num_segments = num_packets;
     if (num_segments == 0 || num_segments > num_packets) return fail(ctx, ALAC_HIP_ParamError, "bad segment count");
-    if (((uintptr_t)d_out & 3) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_pcm & 3))
-        return fail(ctx, ALAC_HIP_ParamError, "misaligned buffer (out/pcm 4 B, workspace 256 B)");
+    if (((uintptr_t)d_out & 3) || ((uintptr_t)d_workspace & 255) || ((uintptr_t)d_pcm & 15))
+        return fail(ctx, ALAC_HIP_ParamError, "misaligned buffer (out 4 B, pcm 16 B, workspace 256 B)");
     const EncLayout L = enc_layout(fmt, num_packets, num_segments);
     if (workspace_bytes < L.total) return fail(ctx, ALAC_HIP_ParamError, "workspace too small");
     if (out_capacity < alac_hip_encode_max_output_bytes(fmt, num_packets))
@@ -248,13 +276,27 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
     pa.frameSize = fmt->frame_size;
     pa.offsets = d_packet_offsets;
     pa.out = d_out;
-    constexpr uint32_t EV = kNumStages + 1;
+    constexpr uint32_t EV = (kMaxSubBatches + 1) * (kNumStages + 1);
     hipEvent_t *ev = nullptr;
     if (ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size()) ev = &ctx->events[ctx->profCalls++ * EV];
     hipError_t e;
     if (use_lane_encoder()) {
-        e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream, ev);
+        if (ev) ctx->profSub.push_back(0);
+        e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream,
+                          ev ? ev + kMaxSubBatches * (kNumStages + 1) : nullptr);
     } else {
+        if (!ctx->vsReady) {
+            ctx->vs.maxSub = kMaxSubBatches;
+            bool ok = hipEventCreateWithFlags(&ctx->vs.fork, hipEventDisableTiming) == hipSuccess;
+            for (uint32_t i = 0; ok && i + 1 < kMaxSubBatches; i++)
+                ok = hipStreamCreateWithFlags(&ctx->vs.side[i], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&ctx->vs.stagger[i], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&ctx->vs.join[i], hipEventDisableTiming) == hipSuccess;
+            if (!ok) return fail(ctx, ALAC_HIP_MemFullError, "creating side streams");
+            ctx->vsReady = true;
+        }
+        ctx->vs.numSub = sub_batches_requested();
+        if (ev) ctx->profSub.push_back(v1_sub_batches(num_segments, ctx->vs.numSub));
         // packets per segment: the pipeline runs once per packet position (a chained segment is serial)
         uint32_t maxSeg = 1;
         if (d_seg_first) {
@@ -278,7 +320,7 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
         vb.bits1 = (uint32_t *)(ws + L.bits1);
         vb.cost2 = (uint32_t *)(ws + L.cost2);
         vb.chainsPad = L.chainsPad;
-        e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, num_packets, maxSeg, ctx->stream, ev);
+        e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, ctx->vs, num_packets, maxSeg, ctx->stream, ev);
     }
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "encode launch", e);
     return ALAC_HIP_noErr;
@@ -297,35 +339,54 @@ int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls)
 {
     if (!ctx) return ALAC_HIP_ParamError;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
-    while (ctx->events.size() < (size_t)max_calls * (kNumStages + 1)) {
+    while (ctx->events.size() < (size_t)max_calls * (kMaxSubBatches + 1) * (kNumStages + 1)) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return fail(ctx, ALAC_HIP_MemFullError, "hipEventCreate");
         ctx->events.push_back(e);
     }
     ctx->profCalls = 0;
+    ctx->profSub.clear();
     ctx->profile = max_calls != 0;
     return ALAC_HIP_noErr;
 }
 
-int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_stage_ms)
+int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_stage_ms, uint32_t *out_launches)
 {
     if (!ctx) return ALAC_HIP_ParamError;
     ctx->profile = false;
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
-    constexpr uint32_t EV = kNumStages + 1;
+    constexpr uint32_t BLK = kNumStages + 1;
+    constexpr uint32_t EV = (kMaxSubBatches + 1) * BLK;
     double t[kNumStages] = {0};
-    for (uint32_t c = 0; c < ctx->profCalls; c++)
-        for (uint32_t k = 0; k < kNumStages; k++) {
-            float ms = 0;
-            e = hipEventElapsedTime(&ms, ctx->events[c * EV + k], ctx->events[c * EV + k + 1]);
-            if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime", e);
-            t[k] += ms;
+    double launches[kNumStages] = {0};
+    auto elapsed = [&](hipEvent_t a, hipEvent_t b, double &acc) -> bool {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return false;
+        acc += ms;
+        return true;
+    };
+    for (uint32_t c = 0; c < ctx->profCalls; c++) {
+        hipEvent_t *base = &ctx->events[(size_t)c * EV];
+        const uint32_t H = ctx->profSub[c];
+        for (uint32_t h = 0; h < H; h++)  // predictor / Golomb stages, one launch per sub-batch
+            for (uint32_t k = kStageLms1; k <= kStageGol3; k++) {
+                if (!elapsed(base[h * BLK + k], base[h * BLK + k + 1], t[k]))
+                    return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime");
+                launches[k] += 1;
+            }
+        hipEvent_t *tail = base + kMaxSubBatches * BLK;
+        for (uint32_t k = (H ? kStageScan : 0); k < kNumStages; k++) {
+            if (!elapsed(tail[k], tail[k + 1], t[k])) return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime");
+            launches[k] += 1;
         }
+    }
     if (out_calls) *out_calls = ctx->profCalls;
     const double n = ctx->profCalls ? ctx->profCalls : 1;
-    if (out_stage_ms)
-        for (uint32_t k = 0; k < kNumStages; k++) out_stage_ms[k] = (float)(t[k] / n);
+    for (uint32_t k = 0; k < kNumStages; k++) {
+        if (out_stage_ms) out_stage_ms[k] = launches[k] > 0 ? (float)(t[k] / launches[k]) : 0.0f;  // per launch
+        if (out_launches) out_launches[k] = (uint32_t)(launches[k] / n + 0.5);                   // per call
+    }
     return ALAC_HIP_noErr;
 }
 

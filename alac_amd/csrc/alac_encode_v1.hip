@@ -24,23 +24,27 @@
 
 namespace alacdev {
 
-constexpr int kTile = 128;        // predictor steps per LDS tile
-constexpr int kHist = 9;          // history kept in front of a tile: in[j-9] is "top" for 8 taps
-constexpr int kXsStride = 168;    // dwords per xs row: >= kHist + kTile, == 8 (mod 32): 4 groups hit disjoint banks
-constexpr int kResStride = 136;   // dwords per residual row, == 8 (mod 32)
+constexpr int kTile = 64;         // predictor steps per LDS tile
+constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; 12 keeps
+                                  // the 16-byte PCM loads of the staging aligned)
+constexpr int kRowLen = kHist + kTile + 4;  // 80 staged samples per row
+constexpr int kXsStride = 89;     // dwords per input row: >= kRowLen + 8 (operand prefetch over-read), odd
+constexpr int kResStride = 65;    // dwords per residual row, odd
+constexpr int kZeroCells = 24;    // zeros fed to lanes that hold no active tap
 
 struct SegView {
     const uint8_t *pcm;
     const uint32_t *numSamples;
     const uint32_t *segFirst;
     uint32_t numSegments, frameSize, pos;
+    uint32_t segBegin, segEnd;  // the sub-batch [segBegin, segEnd) this launch works on
 };
 
 __device__ __forceinline__ bool seg_packet(const SegView &S, uint32_t seg, uint32_t &p, uint32_t &N)
 {
     p = 0;
     N = 0;
-    if (seg >= S.numSegments) return false;
+    if (seg >= S.segEnd) return false;
     const uint32_t p0 = S.segFirst ? S.segFirst[seg] : seg;
     const uint32_t p1 = S.segFirst ? S.segFirst[seg + 1] : seg + 1;
     p = p0 + S.pos;
@@ -57,119 +61,10 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// ---- LDS tile staging ---------------------------------------------------------------------------
-// Fill xs row `row` with x[j0 - kHist .. j0 + kTile) of one chain input: stereo u or v for `mixres`
-// (codec/matrix_enc.cu:72-99 and the 20/24/32-bit forms), or the mono sample.  Out-of-range -> 0.
-template <int DEPTH, int CH>
-__device__ __forceinline__ void stage_rows(int32_t *xs, int rowU, int rowV, const uint8_t *pk, uint32_t N, int mixres,
-                                           int j0, int lane)
-{
-    constexpr int SH = 8 * (int)bytes_shifted(DEPTH);
-    for (int i = lane; i < kHist + kTile; i += 64) {
-        const int j = j0 - kHist + i;
-        int32_t u = 0, v = 0;
-        if (j >= 0 && j < (int)N) {
-            if constexpr (CH == 2) {
-                int32_t l, r;
-                load_lr<DEPTH>(pk, (uint32_t)j, l, r);
-                u = mix_sample(mixres, 0, l, r);
-                v = mix_sample(mixres, 1, l, r);
-            } else {
-                u = load_sample<DEPTH>(pk, (uint32_t)j) >> SH;
-            }
-        }
-        xs[rowU * kXsStride + i] = u;
-        if constexpr (CH == 2) xs[rowV * kXsStride + i] = v;
-    }
-}
-
-// ---- one tile of predictor steps for the 8 chains of the wave --------------------------------------
-// p[j] = in[j] - in[j-1-na] is the same for the 8 taps of a chain: computed once per sample here (8 lanes of
-// the slot x 16 rounds) instead of once per lane per step inside the recurrence loop.
-__device__ __forceinline__ void stage_p(const int32_t *xsRow, int32_t *pRow, int na, int k)
-{
-#pragma unroll
-    for (int i = 0; i < (kTile + 8) / 8; i++) {
-        const int idx = i * 8 + k;  // sample j0 + idx
-        pRow[idx] = xsRow[kHist + idx] - xsRow[kHist + idx - 1 - na];
-    }
-}
-
-// The LDS operands of a step (in[j-1-k], top, p) depend on nothing the recurrence produces, so the
-// operands of block i+1 (8 steps) are fetched into registers while block i computes.
-struct StepOps {
-    int32_t xk[8], tp[8], p[8];
-};
-
-__device__ __forceinline__ void load_ops(StepOps &o, const int32_t *px, const int32_t *pt, const int32_t *pp, int jb)
-{
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        o.xk[s] = px[jb + s];
-        o.tp[s] = pt[jb + s];
-        o.p[s] = pp[jb + s];
-    }
-}
-
-template <bool WIDE, bool MASKED>
-__device__ __forceinline__ void run_block(int32_t &a, const StepOps &o, const LmsLane &L, int jb, int32_t *resAt,
-                                          uint32_t chanbits)
-{
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        const int j = jb + s;
-        const int32_t liveMask = MASKED ? (((j >= L.jlo) & (j < L.jhi)) ? -1 : 0) : -1;
-        // the residual is identical in the 8 lanes of the group: all of them store it (same address, no VALU)
-        resAt[s] = lms8_step<WIDE, MASKED>(a, o.xk[s], o.tp[s], o.p[s], liveMask, L, chanbits);
-    }
-}
-
-template <bool WIDE>
-__device__ __forceinline__ void run_tile(int32_t &a, const int32_t *xsRow, const int32_t *pRow, int32_t *resRow,
-                                         const LmsLane &L, int j0, int jEnd, uint32_t chanbits)
-{
-    // per-lane LDS cursors: x[j] lives at xsRow[kHist + j - j0]; rows are long enough for the one-block
-    // over-read of the prefetch
-    const int kk = L.k < L.na ? L.k : L.na;  // inert taps read "top" so their b is 0
-    const int32_t *px = xsRow + kHist - 1 - kk - j0;
-    const int32_t *pt = xsRow + kHist - 1 - L.na - j0;
-    const int32_t *pp = pRow - j0;
-    StepOps cur, nxt;
-    load_ops(cur, px, pt, pp, j0);
-    for (int jb = j0; jb < jEnd; jb += 8) {
-        load_ops(nxt, px, pt, pp, jb + 8);
-        // wave-uniform: is every lane's chain live for the whole block?
-        const bool allLive = __all((jb >= L.jlo) & (jb + 8 <= L.jhi));
-        if (allLive)
-            run_block<WIDE, false>(a, cur, L, jb, resRow + (jb - j0), chanbits);
-        else
-            run_block<WIDE, true>(a, cur, L, jb, resRow + (jb - j0), chanbits);
-        cur = nxt;
-    }
-}
-
-// warm-up positions of pc_block (dp_enc.c:90, :108-112): pc[0] = in[0], pc[j] = sext(in[j] - in[j-1]), j <= na
-__device__ __forceinline__ void warmup_fix(const int32_t *xsRow, int32_t *resRow, const LmsLane &L, uint32_t chanshift)
-{
-    for (int pos = L.k; pos <= L.na; pos += 8) {
-        const int32_t x = xsRow[kHist + pos];
-        resRow[pos] = pos == 0 ? x : sext(x - xsRow[kHist + pos - 1], chanshift);
-    }
-}
-
-// residual tile -> HBM, [sample][stream] layout
-__device__ __forceinline__ void flush_tile(const int32_t *resRow, int32_t *dst, uint64_t streamStride, uint32_t stream,
-                                           int j0, uint32_t P, int k)
-{
-    int32_t v[kTile / 8];
-#pragma unroll
-    for (int i = 0; i < kTile / 8; i++) v[i] = resRow[i * 8 + k];
-#pragma unroll
-    for (int i = 0; i < kTile / 8; i++) {
-        const uint32_t j = (uint32_t)(j0 + i * 8 + k);
-        if (j < P) dst[(uint64_t)j * streamStride + stream] = v[i];
-    }
-}
+// One wave per workgroup: its LDS operations execute in program order, so phases that hand data through LDS
+// only need the compiler not to reorder them (a real fence would also drain the global loads and stores that
+// are deliberately left in flight across the tile's compute).
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
 struct V1Args {
     SegView S;
@@ -187,197 +82,387 @@ struct V1Args {
 };
 
 // ================================================================================================
-// k_lms_search1 — stereo mixRes search passes (codec/ALACEncoder.cu:353-379)
+// LPC + mix kernels.  One wave = SLOTS chains (64 / LPC), see alac_lms.hpp for the lane mapping.
 // ================================================================================================
+
+// per-wave LDS
+template <int LPC>
+struct LmsShared {
+    static constexpr int SLOTS = 64 / LPC;
+    int32_t xs[SLOTS * kXsStride];      // chain inputs (mixed / widened samples), one row per chain
+    int32_t res[(SLOTS + 1) * kResStride];  // residual tile per chain (+ one dump row for inert lanes)
+    int32_t zero[kZeroCells];
+    uint32_t pktIdx[SLOTS], pktN[SLOTS];  // per input row: packet and its valid samples
+    int32_t rowMix[SLOTS];                // mixRes of the row's packet (this pass)
+};
+
+// Staging of x[j0 - kHist .. j0 + kTile + 4) of every chain of the wave, split in two so that the global
+// loads of tile t+1 are in flight while tile t computes:
+//   stage_load   16-byte PCM loads (4 sample-frames per lane task) into registers
+//   stage_store  stereo mix (codec/matrix_enc.cu:72-99 and the 20/24/32-bit forms) or mono widening, then LDS;
+//                out-of-range samples -> 0
+template <int CH, int LPC>
+struct StageRegs {
+    static constexpr int SLOTS = 64 / LPC;
+    static constexpr int TASKS = (SLOTS / CH) * (kRowLen / 4);  // (packet, 4-sample group) pairs
+    static constexpr int ITERS = (TASKS + 63) / 64;
+    int32_t v[ITERS][4];  // raw PCM words of each task (16-bit: 4 stereo frames / 2 mono pairs; else unused)
+};
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_load(StageRegs<CH, LPC> &R, const LmsShared<LPC> &sh, const uint8_t *pcm,
+                                           uint32_t frameBytes, int j0, int lane)
+{
+    constexpr int GROUPS = kRowLen / 4;
+    if constexpr (DEPTH == 16) {
+        const bool vec = CH == 2 ? (frameBytes & 15) == 0 : (frameBytes & 7) == 0;
+#pragma unroll
+        for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
+            const int idx = it * 64 + lane;
+            const int q = idx / GROUPS, grp = idx - q * GROUPS;
+            const int row = q * CH;
+            R.v[it][0] = R.v[it][1] = R.v[it][2] = R.v[it][3] = 0;
+            if (idx < StageRegs<CH, LPC>::TASKS && vec) {
+                const uint32_t N = sh.pktN[row];
+                const int jb = j0 - kHist + grp * 4;
+                if (jb >= 0 && jb < (int)N) {
+                    const uint8_t *pk = pcm + (uint64_t)sh.pktIdx[row] * frameBytes;
+                    if constexpr (CH == 2) {
+                        const int4 w4 = *(const int4 *)(pk + (uint64_t)jb * 4);
+                        R.v[it][0] = w4.x;
+                        R.v[it][1] = w4.y;
+                        R.v[it][2] = w4.z;
+                        R.v[it][3] = w4.w;
+                    } else {
+                        const int2 w2 = *(const int2 *)(pk + (uint64_t)jb * 2);
+                        R.v[it][0] = w2.x;
+                        R.v[it][1] = w2.y;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShared<LPC> &sh, const uint8_t *pcm,
+                                            uint32_t frameBytes, int j0, int lane)
+{
+    constexpr int GROUPS = kRowLen / 4;
+    constexpr int SH = 8 * (int)bytes_shifted(DEPTH);
+    const bool vec = DEPTH == 16 && (CH == 2 ? (frameBytes & 15) == 0 : (frameBytes & 7) == 0);
+#pragma unroll
+    for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
+        const int idx = it * 64 + lane;
+        if (idx >= StageRegs<CH, LPC>::TASKS) continue;
+        const int q = idx / GROUPS, grp = idx - q * GROUPS;
+        const int row = q * CH;
+        const uint32_t N = sh.pktN[row];
+        const int jb = j0 - kHist + grp * 4;
+        const int mixres = CH == 2 ? sh.rowMix[row] : 0;
+        int32_t u[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+        if (jb >= 0 && jb < (int)N) {
+            if (vec) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool in = jb + t < (int)N;
+                    if constexpr (CH == 2) {
+                        const int32_t l = (int16_t)R.v[it][t], r = R.v[it][t] >> 16;
+                        u[t] = in ? mix_sample(mixres, 0, l, r) : 0;
+                        v[t] = in ? mix_sample(mixres, 1, l, r) : 0;
+                    } else {
+                        const int32_t w = R.v[it][t >> 1];
+                        u[t] = in ? ((t & 1) ? (w >> 16) : (int32_t)(int16_t)w) : 0;
+                    }
+                }
+            } else {
+                const uint8_t *pk = pcm + (uint64_t)sh.pktIdx[row] * frameBytes;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (jb + t < (int)N) {
+                        if constexpr (CH == 2) {
+                            int32_t l, r;
+                            load_lr<DEPTH>(pk, (uint32_t)(jb + t), l, r);
+                            u[t] = mix_sample(mixres, 0, l, r);
+                            v[t] = mix_sample(mixres, 1, l, r);
+                        } else {
+                            u[t] = load_sample<DEPTH>(pk, (uint32_t)(jb + t)) >> SH;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            sh.xs[row * kXsStride + grp * 4 + t] = u[t];
+            if constexpr (CH == 2) sh.xs[(row + 1) * kXsStride + grp * 4 + t] = v[t];
+        }
+    }
+}
+
+// The LDS operands of a step (the sample entering the lane's history window, top, in[j]) depend on nothing
+// the recurrence produces: the operands of block i+1 (8 steps) are fetched while block i computes.
+struct StepOps {
+    int32_t nx[8], tp[8], cu[8];
+};
+
+__device__ __forceinline__ void load_ops(StepOps &o, const int32_t *pn, const int32_t *pt, const int32_t *pc)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        o.nx[s] = pn[s];
+        o.tp[s] = pt[s];
+        o.cu[s] = pc[s];
+    }
+}
+
+template <int LPC, bool MASKED>
+__device__ __forceinline__ void run_block(int32_t (&a)[4], int32_t (&w)[4], const StepOps &o, const LmsLane &L, int jb,
+                                          int32_t *resAt, uint32_t chanbits)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int j = jb + s;
+        const int32_t liveMask = MASKED ? (((j >= L.jlo) & (j < L.jhi)) ? -1 : 0) : -1;
+        resAt[s] = lms4_step<LPC, MASKED>(a, w, o.tp[s], o.cu[s], liveMask, L, chanbits);
+        w[3] = w[2];
+        w[2] = w[1];
+        w[1] = w[0];
+        w[0] = o.nx[s];
+    }
+}
+
+// per-lane view of its chain inside the wave's LDS
+struct LaneView {
+    const int32_t *row;   // xs row of the chain (x[j] at row[kHist + j - j0])
+    int32_t *res;         // residual row (dump row for inert lanes)
+    const int32_t *zero;
+    bool feeds;           // this lane holds at least one active tap
+};
+
+// one tile [j0, jEnd) of steps; the history windows are (re)loaded from LDS at the tile start
+template <int LPC>
+__device__ __forceinline__ void run_tile(int32_t (&a)[4], const LaneView &V, const LmsLane &L, int j0, int jEnd,
+                                         uint32_t chanbits)
+{
+    const int adv = V.feeds ? 1 : 0;
+    // x[j] lives at row[kHist + j - j0].  nx of step j = x[j - 4h] enters the window for step j + 1
+    const int32_t *pn = V.feeds ? V.row + kHist - 4 * L.h : V.zero;
+    const int32_t *pt = V.feeds ? V.row + kHist - 1 - L.na : V.zero;
+    const int32_t *pc = V.row + kHist;
+    int32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = V.feeds ? V.row[kHist - 1 - 4 * L.h - i] : 0;
+    StepOps opA, opB;  // ping-pong: no register copies between blocks
+    load_ops(opA, pn, pt, pc);
+    auto block = [&](const StepOps &cur, StepOps &nxt, int jb) {
+        const int o = jb - j0;
+        load_ops(nxt, pn + adv * (o + 8), pt + adv * (o + 8), pc + (o + 8));
+        const bool allLive = __all((jb >= L.jlo) & (jb + 8 <= L.jhi));  // wave-uniform
+        if (allLive)
+            run_block<LPC, false>(a, w, cur, L, jb, V.res + o, chanbits);
+        else
+            run_block<LPC, true>(a, w, cur, L, jb, V.res + o, chanbits);
+    };
+    for (int jb = j0; jb < jEnd; jb += 16) {
+        block(opA, opB, jb);
+        if (jb + 8 < jEnd) block(opB, opA, jb + 8);
+        else opA = opB;
+    }
+}
+
+// what one wave does in one LPC kernel
+struct ChainJob {
+    bool active;
+    uint32_t seg, ch, p, N;   // chain identity and its packet
+    int na;                   // taps of the row it walks
+    int16_t *row;             // the persistent coefficient row (first tap)
+};
+
+// A pass = one pc_block call over every chain of the wave: `num` samples adapt the row, residual positions
+// j < P go to dst[j * streamStride + stream] when store is set.
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[4],
+                                         uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
+                                         uint32_t stream, int lane)
+{
+    constexpr int SLOTS = 64 / LPC;
+    constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
+    const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
+    const int slot = lane / LPC;
+    LmsLane L = make_lane<LPC>(lane, J.na, J.active ? (int)num : 0);
+    LaneView V;
+    V.feeds = J.active && (4 * L.h < J.na);
+    V.row = sh.xs + slot * kXsStride;
+    V.res = V.feeds ? sh.res + slot * kResStride : sh.res + SLOTS * kResStride;
+    V.zero = sh.zero;
+    // the lane that flushes slot fs = lane % SLOTS needs that slot's P / stream / activity
+    const int fs = lane % SLOTS;
+    const uint32_t fP = (uint32_t)__shfl((int)(J.active ? P : 0), fs * LPC);
+    const uint32_t fStream = (uint32_t)__shfl((int)stream, fs * LPC);
+    const int fNa = __shfl(J.na, fs * LPC);
+    const uint32_t runTo = wave_max(J.active ? (store ? (P > num ? P : num) : num) : 0);
+    StageRegs<CH, LPC> R;
+    if (runTo > 0) {
+        stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+        stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+    }
+    for (int j0 = 0; j0 < (int)runTo; j0 += kTile) {
+        const bool more = j0 + kTile < (int)runTo;
+        if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);  // in flight under the tile
+        lds_order();
+        const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
+        run_tile<LPC>(a, V, L, j0, jEnd, chanBits);
+        lds_order();
+        if (store) {
+            // warm-up positions of pc_block (dp_enc.c:90, :108-112): pc[0] = in[0], pc[j] = sext(in[j] - in[j-1])
+            if (j0 == 0) {
+                for (int pos = lane / SLOTS; pos <= fNa; pos += LPC) {
+                    const int32_t *xr = sh.xs + fs * kXsStride + kHist;
+                    sh.res[fs * kResStride + pos] = pos == 0 ? xr[0] : sext(xr[pos] - xr[pos - 1], 32 - chanBits);
+                }
+                lds_order();
+            }
+            // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams
+#pragma unroll 4
+            for (int it = 0; it < kTile / LPC; it++) {
+                const int jj = it * LPC + lane / SLOTS;
+                const uint32_t j = (uint32_t)(j0 + jj);
+                const int32_t v = sh.res[fs * kResStride + jj];
+                if (j < fP) dst[(uint64_t)j * streamStride + fStream] = v;
+            }
+        }
+        lds_order();
+        if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
+    }
+}
+
+template <int LPC>
+__device__ __forceinline__ void lms_setup(LmsShared<LPC> &sh, const ChainJob &J, int mix, int lane)
+{
+    constexpr int SLOTS = 64 / LPC;
+    if (lane < kZeroCells) sh.zero[lane] = 0;
+    if (lane % LPC == 0) {
+        const int slot = lane / LPC;
+        sh.pktIdx[slot] = J.p;
+        sh.pktN[slot] = J.active ? J.N : 0;
+        sh.rowMix[slot] = mix;
+    }
+    (void)SLOTS;
+    lds_order();
+}
+
+template <int LPC>
+__device__ __forceinline__ void load_row(const ChainJob &J, int32_t (&a)[4], int lane)
+{
+    const int h = LPC == 2 ? (lane & 1) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = (J.active && 4 * h + i < J.na) ? (int32_t)J.row[4 * h + i] : 0;
+}
+
+template <int LPC>
+__device__ __forceinline__ void store_row(const ChainJob &J, const int32_t (&a)[4], int lane)
+{
+    const int h = LPC == 2 ? (lane & 1) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (J.active && 4 * h + i < J.na) J.row[4 * h + i] = (int16_t)a[i];
+}
+
+// ---- k_lms_search1: the five mixRes passes over N/8 samples walking row 7 (codec/ALACEncoder.cu:353-379)
 template <int DEPTH>
 __global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
 {
-    __shared__ int32_t xs[8 * kXsStride];
-    __shared__ int32_t ps[8 * kResStride];
-    __shared__ int32_t res[8 * kResStride];
+    __shared__ LmsShared<2> sh;
     const int lane = threadIdx.x;
-    const int g = lane >> 3, q = g >> 1, c = g & 1;
-    const uint32_t seg = blockIdx.x * 4u + q;
-    uint32_t p, N;
-    const bool active = seg_packet(A.S, seg, p, N);
-    const uint32_t n8 = N / 8;
-    constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + 1;
-    constexpr bool WIDE = chanBits > 17;
-    const uint32_t frameBytes = A.S.frameSize * 2u * bytes_per_sample(DEPTH);
-
-    LmsLane L = make_lane(lane, 8, (int)n8);
-    int16_t *row7 = A.state + (uint64_t)seg * 64 + c * 32 + 16;
-    int32_t a = active ? (int32_t)row7[L.k] : 0;
-    if (!active) L.jhi = 0;
-    const uint32_t maxn8 = wave_max(active ? n8 : 0);
-    const uint32_t chain = seg * 2 + c;
-
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * 2 + blockIdx.x * 32u + lane / 2;
+    J.seg = chain >> 1;
+    J.ch = chain & 1;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = 8;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
+    int32_t a[4];
+    load_row<2>(J, a, lane);
+    const uint32_t n8 = J.N / 8;
     for (int r = 0; r <= kMaxRes; r++) {
-        for (int j0 = 0; j0 < (int)maxn8; j0 += kTile) {
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)p, qq * 16);
-                const uint32_t Nq = (uint32_t)__builtin_amdgcn_readlane((int)N, qq * 16);
-                stage_rows<DEPTH, 2>(xs, 2 * qq, 2 * qq + 1, A.S.pcm + (uint64_t)pq * frameBytes, Nq, r, j0, lane);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            stage_p(xs + g * kXsStride, ps + g * kResStride, L.na, L.k);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const int jEnd = min(j0 + kTile, (int)((maxn8 + 7) & ~7u));
-            run_tile<WIDE>(a, xs + g * kXsStride, ps + g * kResStride, res + g * kResStride, L, j0, jEnd, chanBits);
-            if (j0 == 0) warmup_fix(xs + g * kXsStride, res + g * kResStride, L, 32 - chanBits);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            if (active)
-                flush_tile(res + g * kResStride, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, j0, n8, L.k);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        }
+        lms_setup<2>(sh, J, r, lane);
+        lms_pass<DEPTH, 2, 2>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane);
     }
-    if (active) row7[L.k] = (int16_t)a;
+    store_row<2>(J, a, lane);
 }
 
-// ================================================================================================
-// k_lms_search2 — converge passes for numUV = 4 and 8 (codec/ALACEncoder.cu:420-431; mono :881-893)
-// ================================================================================================
-template <int DEPTH, int CH>
-__global__ __launch_bounds__(64) void k_lms_search2(V1Args A)
+// ---- k_lms_search2: converge passes for numUV = 4 (row 3, one lane per chain) and 8 (row 7, two lanes per
+// chain) in one launch: the first nb3 workgroups take the 4-tap rows (codec/ALACEncoder.cu:420-431; mono :881-893)
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane)
 {
-    __shared__ int32_t xs[4 * kXsStride];
-    __shared__ int32_t ps[8 * kResStride];
-    __shared__ int32_t res[8 * kResStride];
-    const int lane = threadIdx.x;
-    const int g = lane >> 3;
-    const int rs = g & 1;                          // 0: row 3 (4 taps), 1: row 7 (8 taps)
-    const int xrow = g >> 1;                       // LDS input row shared by the two rows of a chain
-    const int q = CH == 2 ? (g >> 2) : (g >> 1);   // segment slot inside the wave
-    const int c = CH == 2 ? ((g >> 1) & 1) : 0;
-    constexpr int SEGS = CH == 2 ? 2 : 4;
-    const uint32_t seg = blockIdx.x * SEGS + q;
-    uint32_t p, N;
-    const bool active = seg_packet(A.S, seg, p, N);
-    const uint32_t n8 = N / 8, n32 = N / 32;
-    constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
-    constexpr bool WIDE = chanBits > 17;
-    const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
-    const int na = rs ? 8 : 4;
-
-    LmsLane L = make_lane(lane, na, (int)n32);
-    int16_t *row = A.state + (uint64_t)seg * 64 + c * 32 + rs * 16;
-    int32_t a = (active && L.k < na) ? (int32_t)row[L.k] : 0;
-    const int best = (CH == 2 && active) ? (int)A.recs[p].mixRes : 0;
-    const uint32_t chain = seg * CH + c;
-
+    constexpr int SLOTS = 64 / LPC;
+    constexpr int rs = LPC == 2 ? 1 : 0;
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * CH + block * SLOTS + lane / LPC;
+    J.seg = chain / CH;
+    J.ch = chain % CH;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = rs ? 8 : 4;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + rs * 16;
+    int32_t a[4];
+    load_row<LPC>(J, a, lane);
+    const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
+    lms_setup<LPC>(sh, J, best, lane);
+    const uint32_t n8 = J.N / 8, n32 = J.N / 32;
     for (int pass = 0; pass < 8; pass++) {
         const bool last = pass == 7;
-        // stereo: every pass runs N/32 samples; mono: the last one runs N/8 (:893)
-        const uint32_t num = (CH == 1 && last) ? n8 : n32;
-        uint32_t P = num > (uint32_t)(na + 1) ? num : (uint32_t)(na + 1);  // positions pc_block writes
-        P = P < n8 ? P : n8;                                               // ... that dyn_comp will read
-        L.jhi = active ? (int)num : 0;
-        const uint32_t runTo = wave_max(active ? (last ? (P > num ? P : num) : num) : 0);
-        if (!last && runTo <= 5) continue;  // nothing adapts (num <= na + 1 for every chain)
-        for (int j0 = 0; j0 < (int)runTo; j0 += kTile) {
-#pragma unroll
-            for (int xr = 0; xr < 4; xr++) {
-                constexpr int lanesPerX = 16;  // two slots (rows 3 and 7) share an input row
-                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)p, xr * lanesPerX);
-                const uint32_t Nq = (uint32_t)__builtin_amdgcn_readlane((int)N, xr * lanesPerX);
-                const int bq = __builtin_amdgcn_readlane(best, xr * lanesPerX);
-                const int cq = CH == 2 ? (xr & 1) : 0;
-                const uint8_t *pk = A.S.pcm + (uint64_t)pq * frameBytes;
-                if constexpr (CH == 2) {
-                    // rows xr = 2*q' + c': stage only the channel this row carries
-                    constexpr int SH = 8 * (int)bytes_shifted(DEPTH);
-                    (void)SH;
-                    for (int i = lane; i < kHist + kTile; i += 64) {
-                        const int j = j0 - kHist + i;
-                        int32_t x = 0;
-                        if (j >= 0 && j < (int)Nq) {
-                            int32_t l, r;
-                            load_lr<DEPTH>(pk, (uint32_t)j, l, r);
-                            x = mix_sample(bq, cq, l, r);
-                        }
-                        xs[xr * kXsStride + i] = x;
-                    }
-                } else {
-                    stage_rows<DEPTH, 1>(xs, xr, xr, pk, Nq, 0, j0, lane);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            stage_p(xs + xrow * kXsStride, ps + g * kResStride, L.na, L.k);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
-            run_tile<WIDE>(a, xs + xrow * kXsStride, ps + g * kResStride, res + g * kResStride, L, j0, jEnd, chanBits);
-            if (last) {
-                if (j0 == 0) warmup_fix(xs + xrow * kXsStride, res + g * kResStride, L, 32 - chanBits);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                if (active)
-                    flush_tile(res + g * kResStride, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain, j0, P, L.k);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        }
+        const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
+        uint32_t P = num > (uint32_t)(J.na + 1) ? num : (uint32_t)(J.na + 1);  // positions pc_block writes ...
+        P = P < n8 ? P : n8;                                                   // ... that dyn_comp will read
+        lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
+                                 lane);
     }
-    if (active && L.k < na) row[L.k] = (int16_t)a;
+    store_row<LPC>(J, a, lane);
 }
 
-// ================================================================================================
-// k_lms_final — final predictor pass with the chosen row (codec/ALACEncoder.cu:505-532, :941)
-// ================================================================================================
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(64) void k_lms_search2(V1Args A, uint32_t nb3)
+{
+    __shared__ union {
+        LmsShared<1> s1;
+        LmsShared<2> s2;
+    } sh;
+    if (blockIdx.x < nb3)
+        search2_body<DEPTH, CH, 1>(sh.s1, A, blockIdx.x, threadIdx.x);
+    else
+        search2_body<DEPTH, CH, 2>(sh.s2, A, blockIdx.x - nb3, threadIdx.x);
+}
+
+// ---- k_lms_final: final pass with the chosen row (codec/ALACEncoder.cu:505-532, :941)
 template <int DEPTH, int CH>
 __global__ __launch_bounds__(64) void k_lms_final(V1Args A)
 {
-    __shared__ int32_t xs[8 * kXsStride];
-    __shared__ int32_t ps[8 * kResStride];
-    __shared__ int32_t res[8 * kResStride];
+    __shared__ LmsShared<2> sh;
     const int lane = threadIdx.x;
-    const int g = lane >> 3;
-    const int q = CH == 2 ? (g >> 1) : g;
-    const int c = CH == 2 ? (g & 1) : 0;
-    constexpr int SEGS = CH == 2 ? 4 : 8;
-    const uint32_t seg = blockIdx.x * SEGS + q;
-    uint32_t p, N;
-    bool active = seg_packet(A.S, seg, p, N);
-    constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
-    constexpr bool WIDE = chanBits > 17;
-    const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
-
-    int na = 4, best = 0;
-    if (active) {
-        const PacketRec *rec = A.recs + p;
-        if (rec->escape) active = false;  // escape estimate: the final pass does not run (:463)
-        na = rec->c[c].num;
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 32u + lane / 2;
+    J.seg = chain / CH;
+    J.ch = chain % CH;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = 4;
+    int best = 0;
+    uint32_t N = J.N;
+    if (J.active) {
+        const PacketRec *rec = A.recs + J.p;
+        J.na = rec->c[J.ch].num;
         best = (int)rec->mixRes;
-    }
-    LmsLane L = make_lane(lane, na, active ? (int)N : 0);
-    int16_t *row = A.state + (uint64_t)seg * 64 + c * 32 + (na == 8 ? 16 : 0);
-    int32_t a = (active && L.k < na) ? (int32_t)row[L.k] : 0;
-    const uint32_t maxN = wave_max(active ? N : 0);
-    const uint32_t chain = seg * CH + c;
-
-    for (int j0 = 0; j0 < (int)maxN; j0 += kTile) {
-        constexpr int ROWS = CH == 2 ? 4 : 8;
-#pragma unroll
-        for (int xr = 0; xr < ROWS; xr++) {
-            constexpr int lanesPerSeg = CH == 2 ? 16 : 8;
-            const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)p, xr * lanesPerSeg);
-            const uint32_t Nq = (uint32_t)__builtin_amdgcn_readlane((int)N, xr * lanesPerSeg);
-            const int bq = __builtin_amdgcn_readlane(best, xr * lanesPerSeg);
-            const uint8_t *pk = A.S.pcm + (uint64_t)pq * frameBytes;
-            if constexpr (CH == 2)
-                stage_rows<DEPTH, 2>(xs, 2 * xr, 2 * xr + 1, pk, Nq, bq, j0, lane);
-            else
-                stage_rows<DEPTH, 1>(xs, xr, xr, pk, Nq, 0, j0, lane);
+        if (rec->escape) {  // escape estimate: the final pass does not run (:463); still stage zeros
+            J.active = false;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        stage_p(xs + g * kXsStride, ps + g * kResStride, L.na, L.k);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        const int jEnd = min(j0 + kTile, (int)((maxN + 7) & ~7u));
-        run_tile<WIDE>(a, xs + g * kXsStride, ps + g * kResStride, res + g * kResStride, L, j0, jEnd, chanBits);
-        if (j0 == 0) warmup_fix(xs + g * kXsStride, res + g * kResStride, L, 32 - chanBits);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (active) flush_tile(res + g * kResStride, A.resC, A.chainsPad, chain, j0, N, L.k);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
-    if (active && L.k < na) row[L.k] = (int16_t)a;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
+    int32_t a[4];
+    load_row<2>(J, a, lane);
+    lms_setup<2>(sh, J, best, lane);
+    lms_pass<DEPTH, CH, 2>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane);
+    store_row<2>(J, a, lane);
 }
 
 // ================================================================================================
@@ -391,10 +476,10 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
     __shared__ uint32_t recip[17];
     gol_table_init(recip, threadIdx.x);
     __syncthreads();
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t chain = t % A.chainsPad, r = t / A.chainsPad;
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, r = blockIdx.y;
+    const uint32_t t = r * A.chainsPad + chain;
     uint32_t p, N;
-    const bool active = (r <= (uint32_t)kMaxRes) && seg_packet(A.S, chain / CH, p, N);
+    const bool active = seg_packet(A.S, chain / CH, p, N);
     const uint32_t n8 = active ? N / 8 : 0;
     const int32_t *src = A.resA + (uint64_t)r * A.chainsPad + chain;
     const uint64_t stride = 5ull * A.chainsPad;
@@ -407,7 +492,7 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
 // codec/ALACEncoder.cu:374-380: first minimum of bits1 + bits2 over mixRes 0..4
 __global__ void k_decide1(V1Args A)
 {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t p, N;
     if (!seg_packet(A.S, seg, p, N)) return;
     uint32_t best = 0, minb = 1u << 31;
@@ -429,10 +514,10 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
     __shared__ uint32_t recip[17];
     gol_table_init(recip, threadIdx.x);
     __syncthreads();
-    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t chain = t % A.chainsPad, rs = t / A.chainsPad;
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, rs = blockIdx.y;
+    const uint32_t t = rs * A.chainsPad + chain;
     uint32_t p, N;
-    const bool active = (rs <= 1) && seg_packet(A.S, chain / CH, p, N);
+    const bool active = seg_packet(A.S, chain / CH, p, N);
     const uint32_t n8 = active ? N / 8 : 0, n32 = N / 32, na = rs ? 8 : 4;
     uint32_t P2 = n8;
     if (CH == 2) {
@@ -454,7 +539,7 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
 template <int DEPTH, int CH>
 __global__ void k_decide2(V1Args A)
 {
-    const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t p, N;
     if (!seg_packet(A.S, seg, p, N)) return;
     PacketRec *rec = A.recs + p;
@@ -489,7 +574,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     __shared__ uint32_t recip[17];
     gol_table_init(recip, threadIdx.x);
     __syncthreads();
-    const uint32_t chain = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x;
     uint32_t p, N;
     bool active = seg_packet(A.S, chain / CH, p, N);
     PacketRec *rec = A.recs + p;
@@ -545,45 +630,80 @@ __global__ void k_init_state(int16_t *state, uint32_t numSegments)
 // ================================================================================================
 template <int DEPTH, int CH>
 static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st,
-                            hipEvent_t *ev, const PackArgs &pa)
+                            hipEvent_t *ev, const PackArgs &pa, const V1Streams &vs)
 {
-    V1Args A = A0;
-    const uint32_t nseg = A.S.numSegments;
     constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
-    const uint32_t streams = A.chainsPad;
-    // stage events are recorded around the last packet position (the only one when every packet is
-    // its own segment)
-    for (uint32_t pos = 0; pos < maxSegPackets; pos++) {
-        A.S.pos = pos;
-        hipEvent_t *e = (ev && pos + 1 == maxSegPackets) ? ev : nullptr;
-        if (e) (void)hipEventRecord(e[kStageLms1], st);
-        if (CH == 2) hipLaunchKernelGGL(k_lms_search1<DEPTH>, dim3((nseg + 3) / 4), dim3(64), 0, st, A);
-        if (e) (void)hipEventRecord(e[kStageGol1], st);
-        if (CH == 2) {
-            hipLaunchKernelGGL(k_gol_count1<CH>, dim3(5 * streams / 64), dim3(64), 0, st, A, chanBits);
-            hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, st, A);
+    const uint32_t nsegAll = A0.S.numSegments;
+    // Sub-batches: the predictor kernels saturate VALU issue while the Golomb kernels are bound by the
+    // latency of one serial chain per lane and leave most SIMDs idle, so sub-batch h+1 starts its predictor
+    // kernels as soon as sub-batch h has finished its first one and the two kinds of kernel overlap.
+    uint32_t H = vs.numSub;
+    if (H < 1) H = 1;
+    while (H > 1 && nsegAll < H * 256) H >>= 1;                 // not worth splitting small batches
+    uint32_t per = ((nsegAll + H - 1) / H + 63) & ~63u;         // whole waves per sub-batch
+    if (H > 1) (void)hipEventRecord(vs.fork, st);
+    for (uint32_t h = 0; h < H; h++) {
+        V1Args A = A0;
+        A.S.segBegin = h * per;
+        A.S.segEnd = (h + 1) * per < nsegAll ? (h + 1) * per : nsegAll;
+        if (A.S.segBegin >= A.S.segEnd) break;
+        const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+        const uint32_t cblocks = (nseg * CH + 63) / 64;
+        hipStream_t sh = h == 0 ? st : vs.side[h - 1];
+        if (h > 0) {
+            (void)hipStreamWaitEvent(sh, vs.fork, 0);
+            (void)hipStreamWaitEvent(sh, vs.stagger[h - 1], 0);  // first predictor kernel of sub-batch h-1 done
         }
-        if (e) (void)hipEventRecord(e[kStageLms2], st);
-        constexpr uint32_t S2 = CH == 2 ? 2 : 4;
-        hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3((nseg + S2 - 1) / S2), dim3(64), 0, st, A);
-        if (e) (void)hipEventRecord(e[kStageGol2], st);
-        hipLaunchKernelGGL(k_gol_count2<CH>, dim3(2 * streams / 64), dim3(64), 0, st, A, chanBits);
-        hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, st, A);
-        if (e) (void)hipEventRecord(e[kStageLms3], st);
-        constexpr uint32_t S3 = CH == 2 ? 4 : 8;
-        hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg + S3 - 1) / S3), dim3(64), 0, st, A);
-        if (e) (void)hipEventRecord(e[kStageGol3], st);
-        hipLaunchKernelGGL(k_gol_final<CH>, dim3(streams / 64), dim3(64), 0, st, A, chanBits);
+        // stage events: sub-batch h records into ev + h * (kNumStages + 1) on its own stream
+        hipEvent_t *evh = ev ? ev + (size_t)h * (kNumStages + 1) : nullptr;
+        for (uint32_t pos = 0; pos < maxSegPackets; pos++) {
+            A.S.pos = pos;
+            hipEvent_t *e = (evh && pos + 1 == maxSegPackets) ? evh : nullptr;
+            const bool firstPos = pos == 0;
+            if (e) (void)hipEventRecord(e[kStageLms1], sh);
+            if (CH == 2) hipLaunchKernelGGL(k_lms_search1<DEPTH>, dim3((nseg * 2 + 31) / 32), dim3(64), 0, sh, A);
+            if (CH == 2 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
+            if (e) (void)hipEventRecord(e[kStageGol1], sh);
+            if (CH == 2) {
+                hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sh, A, chanBits);
+                hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
+            }
+            if (e) (void)hipEventRecord(e[kStageLms2], sh);
+            const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
+            hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sh, A, nb3);
+            if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
+            if (e) (void)hipEventRecord(e[kStageGol2], sh);
+            hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sh, A, chanBits);
+            hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
+            if (e) (void)hipEventRecord(e[kStageLms3], sh);
+            hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sh, A);
+            if (e) (void)hipEventRecord(e[kStageGol3], sh);
+            hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sh, A, chanBits);
+            if (e) (void)hipEventRecord(e[kStageScan], sh);  // end marker of this sub-batch's last stage
+        }
+        if (h > 0) {
+            (void)hipEventRecord(vs.join[h - 1], sh);
+            (void)hipStreamWaitEvent(st, vs.join[h - 1], 0);
+        }
     }
-    if (ev) (void)hipEventRecord(ev[kStageScan], st);
-    hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A.recs, A.packetBytes,
-                       numPackets, A.S.frameSize);
-    launch_scan_pack(DEPTH, CH, A.packetBytes, pa, numPackets, st, ev, false);
+    // sizes, scan, pack: once, on the caller's stream; events live in the slot after the last sub-batch
+    hipEvent_t *evt = ev ? ev + (size_t)vs.maxSub * (kNumStages + 1) : nullptr;
+    if (evt) (void)hipEventRecord(evt[kStageScan], st);
+    hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A0.recs, A0.packetBytes,
+                       numPackets, A0.S.frameSize);
+    launch_scan_pack(DEPTH, CH, A0.packetBytes, pa, numPackets, st, evt, false);
+}
+
+uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested)
+{
+    uint32_t H = requested < 1 ? 1 : requested;
+    while (H > 1 && numSegments < H * 256) H >>= 1;
+    return H;
 }
 
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
-                            const V1Buffers &vb, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st,
-                            hipEvent_t *ev)
+                            const V1Buffers &vb, const V1Streams &vs, uint32_t numPackets, uint32_t maxSegPackets,
+                            hipStream_t st, hipEvent_t *ev)
 {
     V1Args A;
     A.S.pcm = ea.pcm;
@@ -592,6 +712,8 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.S.numSegments = ea.numSegments;
     A.S.frameSize = ea.frameSize;
     A.S.pos = 0;
+    A.S.segBegin = 0;
+    A.S.segEnd = ea.numSegments;
     A.state = vb.state;
     A.recs = ea.recs;
     A.resA = vb.resA;
@@ -609,9 +731,9 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
 #define V1_CASE(D)                                                                                   \
     case D:                                                                                          \
         if (channels == 2)                                                                           \
-            launch_v1_typed<D, 2>(A, numPackets, maxSegPackets, st, ev, pa);                         \
+            launch_v1_typed<D, 2>(A, numPackets, maxSegPackets, st, ev, pa, vs);                         \
         else                                                                                         \
-            launch_v1_typed<D, 1>(A, numPackets, maxSegPackets, st, ev, pa);                         \
+            launch_v1_typed<D, 1>(A, numPackets, maxSegPackets, st, ev, pa, vs);                         \
         break;
     switch (depth) {
         V1_CASE(16)

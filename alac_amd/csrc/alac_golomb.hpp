@@ -119,13 +119,20 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, bool 
     // (C) ag_enc.c:285-331
     if (valid && !swallow) {
         const uint32_t k = min((uint32_t)lg3a(g.mb >> kQBShift), kKB0);
-        const uint32_t rk = recip[k];
         const uint32_t m = (1u << k) - 1;
         const uint32_t a = (uint32_t)(del < 0 ? -del : del);
         const uint32_t t2 = (a << 1) - ((uint32_t)del >> 31);  // n + zmode
         const uint32_t n = t2 - g.zmode;
         const bool esc = n >= m * 9;  // div >= MAX_PREFIX_32
-        const uint32_t div = k == 1 ? n : __umulhi(n, rk);
+        // n / m for m = 2^k - 1, needed only when n < 9 m (else escape).  n = q0 * 2^k + r0 = q0 * m + (q0 + r0)
+        // with q0 <= 8, so for m >= 15 the quotient is q0 or q0 + 1; the three small moduli (1, 3, 7; n < 63)
+        // use an 8-bit reciprocal (256, 86, 37: exact on that range).  No table, no division.
+        const uint32_t q0 = n >> k;
+        const uint32_t t0 = q0 + (n & m);
+        const uint32_t divA = q0 + (t0 >= m ? 1u : 0u);
+        const uint32_t c8 = k == 1 ? 256u : (k == 2 ? 86u : 37u);
+        const uint32_t divB = __umul24(n & 0xffu, c8) >> 8;
+        const uint32_t div = k >= 4 ? divA : divB;
         const uint32_t mod = n - __umul24(div, m);
         const uint32_t de = (mod == 0);
         uint32_t numBits = div + k + 1 - de;
@@ -147,25 +154,37 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, bool 
     }
 }
 
-// Walk one stream of `n` residuals laid out with `stride` (the [sample][stream] planes), 8 samples in
-// flight ahead of the coder so that the global-load latency is paid once per block, not per symbol.
+// Walk one stream of `n` residuals laid out with `stride` (the [sample][stream] planes).  Three 16-sample
+// register buffers rotate so that a block's loads are issued two blocks (32 symbols) before it is coded:
+// the bit-word stores of the coder share the vector-memory counter with the loads, so the compiler can only
+// wait for "everything outstanding" (vmcnt(0)) — with two blocks of distance that wait finds the loads done.
 template <bool WRITE, class Fetch>
 __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
                                             const uint32_t *recip, Fetch &&fetch)
 {
-    int32_t cur[8], nxt[8];
+    constexpr int B = 16;
+    int32_t bufA[B], bufB[B], bufC[B];
+    auto load = [&](int32_t (&buf)[B], uint32_t jb) {
 #pragma unroll
-    for (int s = 0; s < 8; s++) cur[s] = (uint32_t)s < n ? fetch((uint32_t)s) : 0;
-    for (uint32_t jb = 0; jb < nMaxWave; jb += 8) {
+        for (int s = 0; s < B; s++) buf[s] = (jb + s) < n ? fetch(jb + s) : 0;
+    };
+    auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
+        if (jb >= nMaxWave) return;
 #pragma unroll
-        for (int s = 0; s < 8; s++) nxt[s] = (jb + 8 + s) < n ? fetch(jb + 8 + s) : 0;
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
+        for (int s = 0; s < B; s++) {
             const uint32_t j = jb + s;
-            golf_sym<WRITE>(g, cur[s], j < n, j + 1 == n, bitSize, recip);
+            golf_sym<WRITE>(g, buf[s], j < n, j + 1 == n, bitSize, recip);
         }
-#pragma unroll
-        for (int s = 0; s < 8; s++) cur[s] = nxt[s];
+    };
+    load(bufA, 0);
+    load(bufB, B);
+    for (uint32_t jb = 0; jb < nMaxWave; jb += 3 * B) {
+        load(bufC, jb + 2 * B);
+        code(bufA, jb);
+        load(bufA, jb + 3 * B);
+        code(bufB, jb + B);
+        load(bufB, jb + 4 * B);
+        code(bufC, jb + 2 * B);
     }
 }
 

@@ -1,32 +1,31 @@
-// alac_lms.hpp — tap-parallel adaptive predictor for gfx950 (wave64).
+// alac_lms.hpp — the adaptive predictor (pc_block, codec/dp_enc.c:77-388) for gfx950, wave64.
 //
-// One wavefront walks 8 predictor chains at once: lane = (slot g = lane >> 3, tap k = lane & 7).
-// Per step the 8 taps of a chain form their products in parallel and the sum is reduced with a
-// three-stage DPP butterfly (quad_perm xor 1, xor 2, row_half_mirror) — no LDS traffic for the
-// reduction.  Only the coefficient recurrence is serial; everything that depends on the input data
-// alone (tap differences b_k, the early-exit thresholds of the sign-LMS update) is computed off the
-// dependent chain.
+// Lane mapping: a chain (one channel of one packet) owns LPC adjacent lanes, each lane holds 4 taps
+// (coefficients and the matching 4-sample history window in registers):
+//   LPC = 2   8-tap rows: lane h = 0 holds taps 0..3, lane h = 1 taps 4..7; the tap sum of a step is the
+//             in-lane 4-term multiply-add chain plus ONE cross-lane add (DPP quad_perm xor 1)
+//   LPC = 1   4-tap rows: the whole chain lives in one lane, no cross-lane traffic at all
+// so a wave walks 32 (LPC 2) or 64 (LPC 1) chains at once.  With 10 000 stereo packets that is 625 waves,
+// i.e. at most one wave per SIMD on 1024 SIMDs: the cost of a step is this wave's own instruction count,
+// which is why the taps are folded into the lanes instead of being spread over 8 lanes each.
 //
-// Reference recurrence: pc_block, codec/dp_enc.c:77-388 (4-tap :116-195, 8-tap :196-340, general
-// :341-387 are the same recurrence).  The update loop "walk taps k = na-1 .. 0 while del0 keeps its
-// sign" (:143-188) is evaluated without the walk: with t_k = |b_k| >> 9 (del > 0) resp.
-// (|b_k| + 511) >> 9 (del < 0) [= -((-|b_k|) >> 9)], tap k is touched iff
-// |del| > S_k := sum_{i > k} (na - i) * t_i, because the partial sums only grow.  S_k for both signs
-// is an exclusive suffix scan over the 8 lanes of the group (masked DPP butterfly, 7 instructions).
+// The early-exit update walk of the reference ("for k = na-1 .. 0 while del0 keeps its sign",
+// dp_enc.c:143-188) is evaluated without the walk: with t_i = |b_i| >> 9 (del > 0) resp.
+// (|b_i| + 511) >> 9 (del < 0) [= -((-|b_i|) >> 9)], tap k is touched iff
+// |del| > S_k := sum_{i > k} (na - i) * t_i, because the partial sums only grow.  Everything that depends
+// on the input samples alone (b_i, S_k for both signs, sign(b_i)) is off the dependent chain, which is just
+// multiply-add -> (pair add) -> shift/add/sign-extend -> clamp-compare -> coefficient add.
 #pragma once
 
 #include "alac_dev.hpp"
 
 namespace alacdev {
 
-constexpr int kDppXor1 = 0xB1;        // quad_perm:[1,0,3,2]
-constexpr int kDppXor2 = 0x4E;        // quad_perm:[2,3,0,1]
-constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane i <-> 7 - i inside each 8 lanes
+constexpr int kDppXor1 = 0xB1;  // quad_perm:[1,0,3,2]: partner lane of a 2-lane chain
 
-template <int CTRL, int RM = 0xf, int BM = 0xf>
-__device__ __forceinline__ int32_t dpp_z(int32_t src)
+__device__ __forceinline__ int32_t dpp_xor1(int32_t src)
 {
-    return __builtin_amdgcn_update_dpp(0, src, CTRL, RM, BM, true);
+    return __builtin_amdgcn_update_dpp(0, src, kDppXor1, 0xf, 0xf, true);
 }
 
 __device__ __forceinline__ int32_t med3_i32(int32_t x, int32_t lo, int32_t hi)
@@ -36,58 +35,6 @@ __device__ __forceinline__ int32_t med3_i32(int32_t x, int32_t lo, int32_t hi)
     return r;
 }
 
-// all-reduce add over the 8 lanes of a group
-__device__ __forceinline__ int32_t group_sum8(int32_t v)
-{
-    v += dpp_z<kDppXor1>(v);
-    v += dpp_z<kDppXor2>(v);
-    v += dpp_z<kDppHalfMirror>(v);
-    return v;
-}
-
-// exclusive suffix sum over the 8 lanes of a group: out_k = sum_{i > k} w_i
-//   modd = ~0 on odd taps, mk1 = ~0 on taps with bit 1 set (per-lane constants)
-__device__ __forceinline__ uint32_t group_suffix_excl8(uint32_t w, uint32_t modd, uint32_t mk1)
-{
-    const uint32_t pair = w + (uint32_t)dpp_z<kDppXor1>((int32_t)w);
-    const uint32_t quad = pair + (uint32_t)dpp_z<kDppXor2>((int32_t)pair);
-    uint32_t s = (uint32_t)dpp_z<kDppXor1>((int32_t)(w & modd));       // even taps: w_{k+1}
-    s += (uint32_t)dpp_z<kDppXor2>((int32_t)(pair & mk1));              // taps 0,1 / 4,5: upper pair of the quad
-    s += (uint32_t)dpp_z<kDppHalfMirror, 0xf, 0x5>((int32_t)quad);      // taps 0..3: the upper quad
-    return s;
-}
-
-// per-lane constants of a chain slot
-struct LmsLane {
-    int32_t k;        // tap index 0..7
-    int32_t na;       // taps of this chain (4 or 8); lanes k >= na are inert (their b is forced to 0)
-    int32_t wk;       // na - k for k < na, else 0
-    int32_t c255;     // 255 on tap 0: folds "denhalf - sum" into the product (see lms8_step)
-    uint32_t modd, mk1;
-    int32_t jlo, jhi; // coefficients adapt for jlo <= j < jhi  (jlo = na + 1, jhi = pc_block's num)
-};
-
-__device__ __forceinline__ LmsLane make_lane(int lane, int na, int num)
-{
-    LmsLane L;
-    L.k = lane & 7;
-    L.na = na;
-    L.wk = L.k < na ? na - L.k : 0;
-    L.c255 = L.k == 0 ? 255 : 0;
-    L.modd = (L.k & 1) ? ~0u : 0u;
-    L.mk1 = (L.k & 2) ? ~0u : 0u;
-    L.jlo = na + 1;
-    L.jhi = num;
-    return L;
-}
-
-// One predictor step of all 8 chains of the wave.
-//   a    this lane's coefficient (int16 value kept in an int32)
-//   xk   in[j-1-k]  (taps k >= na are handed in[j-1-na] so that b = 0)
-//   tp   in[j-1-na] ("top"),  p = in[j] - top (same for the 8 taps: computed once per sample at staging)
-// Returns the residual (identical in the 8 lanes of a group).
-//   sum1 = (denhalf - sum) >> 9 and del = in[j] - top - sum1 (dp_enc.c:136-139) are folded into
-//   del = (in[j] - top) + ((sum + 255) >> 9): -floor((256 - s)/512) == floor((s + 255)/512).
 // sign(x) as clamp(x, -1, 1) in one v_med3_i32 with inline constants
 __device__ __forceinline__ int32_t sign3(int32_t x)
 {
@@ -96,34 +43,90 @@ __device__ __forceinline__ int32_t sign3(int32_t x)
     return r;
 }
 
-template <bool WIDE, bool MASKED>
-__device__ __forceinline__ int32_t lms8_step(int32_t &a, int32_t xk, int32_t tp, int32_t p, int32_t liveMask,
-                                             const LmsLane &L, uint32_t chanbits)
+// per-lane constants of a chain
+struct LmsLane {
+    int32_t h;         // which half of the taps this lane holds (always 0 for LPC = 1)
+    int32_t na;        // taps of the chain (4 or 8)
+    int32_t wg[4];     // update weights na - (4h + i), 0 for taps >= na
+    int32_t c255;      // 255 on the lane holding tap 0: folds "denhalf - sum" into the product chain
+    int32_t carryMask; // ~0 on h = 0 lanes of a 2-lane chain: they take the partner's threshold totals
+    int32_t jlo, jhi;  // coefficients adapt for jlo <= j < jhi (jlo = na + 1, jhi = pc_block's num)
+};
+
+template <int LPC>
+__device__ __forceinline__ LmsLane make_lane(int lane, int na, int num)
 {
-    // ---- data-only part (off the dependent chain) ----
-    const int32_t b = tp - xk;
-    const int32_t ab = max(b, -b);
-    const uint32_t tpos = (uint32_t)ab >> kDenShift;
-    const uint32_t tneg = (uint32_t)(ab + ((1 << kDenShift) - 1)) >> kDenShift;
-    int32_t hi, lo;
-    if constexpr (!WIDE) {
-        // chanbits <= 17: |b| < 2^17 so t <= 256 and every suffix sum < 2^14: both signs share one scan
-        const uint32_t w = __umul24(tpos | (tneg << 14), (uint32_t)L.wk);
-        const uint32_t s = group_suffix_excl8(w, L.modd, L.mk1);
-        hi = (int32_t)(s & 0x3fffu);
-        lo = -(int32_t)(s >> 14);
-    } else {
-        hi = (int32_t)group_suffix_excl8(__umul24(tpos, (uint32_t)L.wk), L.modd, L.mk1);
-        lo = -(int32_t)group_suffix_excl8(__umul24(tneg, (uint32_t)L.wk), L.modd, L.mk1);
+    LmsLane L;
+    L.h = LPC == 2 ? (lane & 1) : 0;
+    L.na = na;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int kk = 4 * L.h + i;
+        L.wg[i] = kk < na ? na - kk : 0;
     }
-    int32_t sb = sign3(b);
-    if constexpr (MASKED) sb &= liveMask;  // steps outside [jlo, jhi) leave the coefficients alone
+    L.c255 = L.h == 0 ? 255 : 0;
+    L.carryMask = (LPC == 2 && L.h == 0) ? -1 : 0;
+    L.jlo = na + 1;
+    L.jhi = num;
+    return L;
+}
+
+// One predictor step of every chain of the wave.
+//   a[i]  coefficient of tap 4h+i (int16 value carried in an int32; the wrap is applied where it is read)
+//   w[i]  in[j-1-(4h+i)]   (lanes holding no active tap are fed zeros: b = 0, nothing happens)
+//   tp    in[j-1-na] ("top"),  cu = in[j]
+// Returns the residual.  sum1 = (denhalf - sum) >> 9 and del = in[j] - top - sum1 (dp_enc.c:136-139)
+// are folded into del = (in[j] - top) + ((sum + 255) >> 9): -floor((256 - s)/512) == floor((s + 255)/512).
+template <int LPC, bool MASKED>
+__device__ __forceinline__ int32_t lms4_step(int32_t (&a)[4], const int32_t (&w)[4], int32_t tp, int32_t cu,
+                                             int32_t liveMask, const LmsLane &L, uint32_t chanbits)
+{
+    // ---- data-only part ----
+    int32_t b[4], sb[4];
+    uint32_t tpos[4], tneg[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b[i] = tp - w[i];
+        const int32_t ab = max(b[i], -b[i]);
+        tpos[i] = (uint32_t)ab >> kDenShift;
+        tneg[i] = (uint32_t)(ab + ((1 << kDenShift) - 1)) >> kDenShift;
+        sb[i] = sign3(b[i]);
+        if constexpr (MASKED) sb[i] &= liveMask;  // steps outside [jlo, jhi) leave the coefficients alone
+    }
+    // thresholds: hi[i] = S+_{4h+i}, lo[i] = -S-_{4h+i}: in-lane running sums from the top tap down
+    int32_t hi[4], lo[4];
+    hi[3] = 0;
+    lo[3] = 0;
+#pragma unroll
+    for (int i = 3; i > 0; i--) {
+        hi[i - 1] = (int32_t)__umul24(tpos[i], (uint32_t)L.wg[i]) + hi[i];
+        lo[i - 1] = lo[i] - (int32_t)__umul24(tneg[i], (uint32_t)L.wg[i]);
+    }
+    if constexpr (LPC == 2) {
+        // taps 0..3 also count everything the partner lane (taps 4..7) holds
+        const int32_t totP = (int32_t)__umul24(tpos[0], (uint32_t)L.wg[0]) + hi[0];
+        const int32_t totM = lo[0] - (int32_t)__umul24(tneg[0], (uint32_t)L.wg[0]);
+        const int32_t cP = dpp_xor1(totP) & L.carryMask;
+        const int32_t cM = dpp_xor1(totM) & L.carryMask;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            hi[i] += cP;
+            lo[i] += cM;
+        }
+    }
+    const int32_t p = cu - tp;
 
     // ---- dependent chain ----
-    const int32_t s = group_sum8(__mul24((int32_t)(int16_t)a, b) + L.c255);
+    int32_t s = L.c255;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;
+    if constexpr (LPC == 2) s += dpp_xor1(s);
     const int32_t del = __builtin_amdgcn_sbfe(p + (s >> kDenShift), 0, chanbits);
-    const int32_t e = med3_i32(del, lo, hi) - del;  // < 0: del > S+ (positive side), > 0: del < -S-
-    a = __mul24(sign3(e), sb) + a;                  // a -= sign(del) * sign(b) on the touched taps
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int32_t e = med3_i32(del, lo[i], hi[i]) - del;  // < 0: del > S+ ; > 0: del < -S-
+        a[i] = __mul24(sign3(e), sb[i]) + a[i];               // a -= sign(del) * sign(b) on the touched taps
+    }
     return del;
 }
 

@@ -97,8 +97,11 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
  * codec/CudaAlacEncoder.cu:52-65).  begin() arms up to max_calls encode calls; end() synchronises and
  * returns the number of calls timed and the mean milliseconds of every pipeline stage. */
 int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls);
-/* out_stage_ms: [alac_hip_num_stages()] mean milliseconds per pipeline stage (alac_hip_stage_name(i)) */
-int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_stage_ms);
+/* out_stage_ms: [alac_hip_num_stages()] mean milliseconds of ONE launch of each pipeline stage
+ * (alac_hip_stage_name(i)); out_launches: launches of that stage per encode call (the predictor and
+ * Golomb stages run once per overlapped sub-batch). */
+int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_stage_ms,
+                             uint32_t *out_launches);
 uint32_t alac_hip_num_stages(void);
 const char *alac_hip_stage_name(uint32_t stage);
 
