@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=16)
     ap.add_argument("--cpu-packets", type=int, default=10000, help="size of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-reassemble", action="store_true", help="skip the RCCL re-assembly at N > 1")
+    ap.add_argument("--force-reassemble", action="store_true",
+                    help="rehearsal: run the RCCL re-assembly path even with one rank (needs torch.distributed.run)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,8 +71,10 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_reassemble
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     fmt = alac_amd.make_format(4096, args.bit_depth, 2, 44100)
@@ -81,14 +85,14 @@ def main():
     pcm_host = alac_amd.synth_pcm(rank * B, B, fmt)
     d_pcm = torch.from_numpy(pcm_host).cuda()
     bufs = [ctx.encode_buffers(fmt, B) for _ in range(2)]
-    comm_stream = torch.cuda.Stream() if world > 1 else None
+    comm_stream = torch.cuda.Stream() if use_dist else None
     gather = None
 
     def step(i):
         nonlocal gather
         b = bufs[i & 1]
         ctx.encode(fmt, d_pcm, B, bufs=b)
-        if world > 1 and not args.no_reassemble:
+        if use_dist and not args.no_reassemble:
             # re-assembly of step i runs on the side stream under the encode of step i+1
             ev = torch.cuda.Event()
             ev.record()
@@ -110,7 +114,7 @@ def main():
         wait_reuse(i)
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -120,14 +124,14 @@ def main():
         wait_reuse(i)
         last = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     calls, stage_ms = ctx.profile_end()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -211,7 +215,12 @@ def main():
             out["bit_exact_vs_cpu"] = exact
             out["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if rank == 0 and use_dist and not args.no_reassemble and gather is not None:
+        # the re-assembled stream on this rank must be the rank-ordered concatenation; rank 0's own shard leads it
+        n0 = int(last["offsets"][-1].item())
+        ok = bool(torch.equal(gather["stream"][:n0], last["out"][:n0])) and gather["total"] >= n0
+        print(json.dumps({"reassembly_check": ok, "stream_bytes": gather["total"]}), file=sys.stderr, flush=True)
+    if use_dist:
         dist.destroy_process_group()
 
 
