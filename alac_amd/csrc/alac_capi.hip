@@ -60,7 +60,7 @@ struct EncLayout {
     uint32_t wcap;
     uint64_t predStride;
     // tap-parallel pipeline: residual planes [sample][stream], decision scratch, working state
-    uint64_t resA, resB, resC, bits1, cost2, state;
+    uint64_t resA, resB, resC, bits1, cost2, state, flags;
     uint32_t chainsPad;
 };
 
@@ -93,6 +93,8 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     off = align_up(off + 2 * lanes * 4, 256);
     L.state = off;
     off = align_up(off + (uint64_t)numSegments * 128, 256);
+    L.flags = off;
+    off = align_up(off + (lanes / 32 + 4) * 4, 256);
     L.total = off;
     return L;
 }
@@ -319,6 +321,7 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
         vb.resC = (int32_t *)(ws + L.resC);
         vb.bits1 = (uint32_t *)(ws + L.bits1);
         vb.cost2 = (uint32_t *)(ws + L.cost2);
+        vb.flags = (uint32_t *)(ws + L.flags);
         vb.chainsPad = L.chainsPad;
         e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, ctx->vs, num_packets, maxSeg, ctx->stream, ev);
     }

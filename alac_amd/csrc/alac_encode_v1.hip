@@ -17,6 +17,7 @@
 // the lane-per-stream Golomb kernels read them coalesced.
 //
 // Reference control flow: codec/ALACEncoder.cu:290-558 (EncodeStereo), :812-963 (EncodeMono).
+#include <cstdlib>
 #include "alac_dev.hpp"
 #include "alac_kernels.hpp"
 #include "alac_lms.hpp"
@@ -66,6 +67,42 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // are deliberately left in flight across the tile's compute).
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
+// ---- producer -> consumer hand-off inside one launch (cdna_hip_programming.md Guideline 16) ----
+// The residual rows are stored with agent-scope atomic stores (global_store ... sc1: written through the
+// XCD's L2), so once `s_waitcnt vmcnt(0)` has seen them complete there is nothing left in this L2 for a
+// release to write back, and the flag can follow directly.  Measured: an agent-scope release fence here
+// (buffer_wbl2 of the WHOLE L2, which also holds the coder waves' dirty bit words) costs ~11 us per
+// publish; ALAC_HIP_PUBFENCE=1 puts it back (and publishes every 4 tiles instead of every tile).
+__device__ __forceinline__ void publish_rows(uint32_t *flag, uint32_t rows, int lane, bool fence)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (fence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) __hip_atomic_store(flag, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Consumer: relaxed poll of the (two) producer words, then ONE agent-scope acquire before any newly
+// published row is loaded.  Bounded spin: a lost producer yields wrong packets (caught by parity), not a hang.
+struct RowWait {
+    const uint32_t *f0, *f1;
+    uint32_t avail, base;
+    __device__ __forceinline__ void operator()(uint32_t rows)
+    {
+        rows += base;
+        if (avail >= rows) return;
+        for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+            const uint32_t a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t b = f1 ? __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a < b ? a : b));
+            if (avail >= rows) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+};
+
 struct V1Args {
     SegView S;
     int16_t *state;        // [segment][64] working coefficient rows
@@ -79,6 +116,8 @@ struct V1Args {
     uint32_t *bitWords;
     uint32_t wcap;
     uint32_t *packetBytes;
+    uint32_t *flags;       // producer progress words of the fused final kernel (zeroed per call)
+    uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
 };
 
 // ================================================================================================
@@ -284,7 +323,7 @@ struct ChainJob {
 template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[4],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
-                                         uint32_t stream, int lane)
+                                         uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0)
 {
     constexpr int SLOTS = 64 / LPC;
     constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
@@ -329,8 +368,15 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 const int jj = it * LPC + lane / SLOTS;
                 const uint32_t j = (uint32_t)(j0 + jj);
                 const int32_t v = sh.res[fs * kResStride + jj];
-                if (j < fP) dst[(uint64_t)j * streamStride + fStream] = v;
+                if (j < fP) {
+                    int32_t *q = dst + (uint64_t)j * streamStride + fStream;
+                    // fused final: write through (agent scope) so that the release below finds little to write back
+                    if (flag) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *q = v;
+                }
             }
+            // fused final kernel: tell the coder waves how many residual rows are complete (every 4 tiles)
+            if (flag && ((((j0 / kTile) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + kTile, (int)runTo), lane, (A.pubMask >> 31) != 0);
         }
         lds_order();
         if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
@@ -489,6 +535,56 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
     if (active) A.bits1[t] = g.bits;
 }
 
+// ---- k_search1_fused: k_lms_search1 and k_gol_count1 in one launch.  Workgroups [0, nLms) walk the five
+// mixRes passes and publish (pass << 16) + rows; the count waves of pass r follow them through plane r.
+template <int DEPTH>
+__global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, uint32_t cblocks, uint32_t chanBits)
+{
+    __shared__ LmsShared<2> sh;
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    if (blockIdx.x < nLms) {
+        ChainJob J;
+        const uint32_t chain = A.S.segBegin * 2 + blockIdx.x * 32u + lane / 2;
+        J.seg = chain >> 1;
+        J.ch = chain & 1;
+        J.active = seg_packet(A.S, J.seg, J.p, J.N);
+        J.na = 8;
+        J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
+        int32_t a[4];
+        load_row<2>(J, a, lane);
+        const uint32_t n8 = J.N / 8;
+        uint32_t *flag = A.flags + blockIdx.x;
+        for (int r = 0; r <= kMaxRes; r++) {
+            lms_setup<2>(sh, J, r, lane);
+            lms_pass<DEPTH, 2, 2>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
+                                  flag, (uint32_t)r << 16);
+        }
+        store_row<2>(J, a, lane);
+        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);
+    } else {
+        gol_table_init(recip, lane);
+        __syncthreads();
+        const uint32_t idx = blockIdx.x - nLms, r = idx / cblocks, w = idx % cblocks;
+        const uint32_t chain = A.S.segBegin * 2 + w * 64u + lane;
+        const uint32_t t = r * A.chainsPad + chain;
+        uint32_t p, N;
+        const bool active = seg_packet(A.S, chain >> 1, p, N);
+        const uint32_t n8 = active ? N / 8 : 0;
+        const int32_t *src = A.resA + (uint64_t)r * A.chainsPad + chain;
+        const uint64_t stride = 5ull * A.chainsPad;
+        GolF g;
+        golf_reset(g);
+        RowWait wait;
+        wait.f0 = A.flags + 2 * w;
+        wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
+        wait.avail = 0;
+        wait.base = r << 16;
+        golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return src[j * stride]; }, wait);
+        if (active) A.bits1[t] = g.bits;
+    }
+}
+
 // codec/ALACEncoder.cu:374-380: first minimum of bits1 + bits2 over mixRes 0..4
 __global__ void k_decide1(V1Args A)
 {
@@ -592,6 +688,68 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     if (active) rec->c[c].bits = g.bits;
 }
 
+// ---- k_final_fused: the final predictor pass and the final entropy coder in ONE launch.  Workgroups
+// [0, nLms) are predictor waves (32 chains each), the rest are coder waves (64 chains each) that follow their
+// two producers through the residual plane, 256 samples behind.  Both kinds are single-wave workgroups and
+// together (625 + 313 at 10k packets) still fit one per SIMD, so the ~1.0 ms and ~1.3 ms of the two stages
+// overlap instead of adding up.
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits)
+{
+    __shared__ LmsShared<2> sh;
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    if (blockIdx.x < nLms) {
+        ChainJob J;
+        const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 32u + lane / 2;
+        J.seg = chain / CH;
+        J.ch = chain % CH;
+        J.active = seg_packet(A.S, J.seg, J.p, J.N);
+        J.na = 4;
+        int best = 0;
+        const uint32_t N = J.N;
+        if (J.active) {
+            const PacketRec *rec = A.recs + J.p;
+            J.na = rec->c[J.ch].num;
+            best = (int)rec->mixRes;
+            if (rec->escape) J.active = false;
+        }
+        J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
+        int32_t a[4];
+        load_row<2>(J, a, lane);
+        lms_setup<2>(sh, J, best, lane);
+        uint32_t *flag = A.flags + blockIdx.x;
+        lms_pass<DEPTH, CH, 2>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
+        store_row<2>(J, a, lane);
+        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);  // nothing more will come (also covers inactive waves)
+    } else {
+        gol_table_init(recip, lane);
+        __syncthreads();
+        const uint32_t w = blockIdx.x - nLms;
+        const uint32_t chain = A.S.segBegin * CH + w * 64u + lane;
+        uint32_t p, N;
+        bool active = seg_packet(A.S, chain / CH, p, N);
+        PacketRec *rec = A.recs + p;
+        if (active && rec->escape) active = false;
+        const uint32_t c = chain % CH;
+        const uint32_t n = active ? N : 0;
+        const int32_t *src = A.resC + chain;
+        const uint64_t stride = A.chainsPad;
+        GolF g;
+        golf_reset(g);
+        g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
+        g.wcap = A.wcap;
+        RowWait wait;
+        wait.f0 = A.flags + 2 * w;
+        wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
+        wait.avail = 0;
+        wait.base = 0;
+        golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return src[j * stride]; }, wait);
+        golf_flush<true>(g);
+        if (active) rec->c[c].bits = g.bits;
+    }
+}
+
 // packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)
 template <int DEPTH, int CH>
 __global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numPackets, uint32_t frameSize)
@@ -661,12 +819,24 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             hipEvent_t *e = (evh && pos + 1 == maxSegPackets) ? evh : nullptr;
             const bool firstPos = pos == 0;
             if (e) (void)hipEventRecord(e[kStageLms1], sh);
-            if (CH == 2) hipLaunchKernelGGL(k_lms_search1<DEPTH>, dim3((nseg * 2 + 31) / 32), dim3(64), 0, sh, A);
-            if (CH == 2 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
-            if (e) (void)hipEventRecord(e[kStageGol1], sh);
-            if (CH == 2) {
-                hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sh, A, chanBits);
+            static const bool fused = [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
+            const bool fuse = fused && H == 1;  // flag words are indexed by workgroup: one sub-batch only
+            const uint32_t nLms = (nseg * CH + 31) / 32;
+            if constexpr (CH == 2) {
+                if (fuse) {
+                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
+                    hipLaunchKernelGGL(k_search1_fused<DEPTH>, dim3(nLms + 5 * cblocks), dim3(64), 0, sh, A, nLms, cblocks,
+                                       chanBits);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sh);
+                } else {
+                    hipLaunchKernelGGL(k_lms_search1<DEPTH>, dim3(nLms), dim3(64), 0, sh, A);
+                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sh);
+                    hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sh, A, chanBits);
+                }
                 hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
+            } else if (e) {
+                (void)hipEventRecord(e[kStageGol1], sh);
             }
             if (e) (void)hipEventRecord(e[kStageLms2], sh);
             const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
@@ -676,9 +846,15 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sh, A, chanBits);
             hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
             if (e) (void)hipEventRecord(e[kStageLms3], sh);
-            hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sh, A);
-            if (e) (void)hipEventRecord(e[kStageGol3], sh);
-            hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sh, A, chanBits);
+            if (fuse) {
+                (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sh, A, nLms, chanBits);
+                if (e) (void)hipEventRecord(e[kStageGol3], sh);
+            } else {
+                hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sh, A);
+                if (e) (void)hipEventRecord(e[kStageGol3], sh);
+                hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sh, A, chanBits);
+            }
             if (e) (void)hipEventRecord(e[kStageScan], sh);  // end marker of this sub-batch's last stage
         }
         if (h > 0) {
@@ -725,6 +901,14 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.bitWords = ea.bitWords;
     A.wcap = ea.wcap;
     A.packetBytes = ea.packetBytes;
+    A.flags = vb.flags;
+    {
+        static const uint32_t pm = [] {
+            const char *v = getenv("ALAC_HIP_PUBFENCE");
+            return (v && v[0] == '1') ? (0x80000000u | 3u) : 0u;
+        }();
+        A.pubMask = pm;
+    }
     if (!vb.stateInitialised)
         hipLaunchKernelGGL(k_init_state, dim3((ea.numSegments * 64 + 255) / 256), dim3(256), 0, st, vb.state,
                            ea.numSegments);

@@ -158,13 +158,20 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, bool 
 // register buffers rotate so that a block's loads are issued two blocks (32 symbols) before it is coded:
 // the bit-word stores of the coder share the vector-memory counter with the loads, so the compiler can only
 // wait for "everything outstanding" (vmcnt(0)) — with two blocks of distance that wait finds the loads done.
-template <bool WRITE, class Fetch>
+// `need(rows)` is called (wave-uniformly) before rows < `rows` of the plane are read: a no-op when the plane was
+// written by an earlier kernel, a flag wait + acquire when a producer in the same launch is still writing it.
+struct NoWait {
+    __device__ __forceinline__ void operator()(uint32_t) const {}
+};
+
+template <bool WRITE, class Fetch, class Need = NoWait>
 __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
-                                            const uint32_t *recip, Fetch &&fetch)
+                                            const uint32_t *recip, Fetch &&fetch, Need &&need = Need())
 {
     constexpr int B = 16;
     int32_t bufA[B], bufB[B], bufC[B];
     auto load = [&](int32_t (&buf)[B], uint32_t jb) {
+        if (jb < nMaxWave) need(min(jb + B, nMaxWave));
 #pragma unroll
         for (int s = 0; s < B; s++) buf[s] = (jb + s) < n ? fetch(jb + s) : 0;
     };

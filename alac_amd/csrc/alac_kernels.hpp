@@ -76,6 +76,7 @@ struct V1Buffers {
     bool stateInitialised; // rows already hold the caller's initial state
     int32_t *resA, *resB, *resC;
     uint32_t *bits1, *cost2;
+    uint32_t *flags;       // [chains / 32] progress words of the fused final kernel
     uint32_t chainsPad;
 };
 // side streams and fork/join events for the sub-batch overlap (owned by the context)
