@@ -62,6 +62,8 @@ SIGNATURES = {
     "alac_hip_dyn_decomp": (_i32, [_vp, _u32, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _i32, _i32, _vp, _vp]),
     "alac_hip_encode_host": (_i32, [_vp, C.POINTER(Format), _vp, _u64, _u32, _vp, _i32, _vp, _u64, _vp,
                                     C.POINTER(_u64)]),
+    "alac_hip_encode_host_segments": (_i32, [_vp, C.POINTER(Format), _vp, _vp, _u32, _vp, _u32, _vp, _i32, _vp, _u64, _vp,
+                                             C.POINTER(_u64)]),
     "alac_hip_decode_host": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _vp]),
     "alac_synth_frame": (None, [_u64, _u32, _u32, _u32, _vp]),
     "alac_synth_pcm": (None, [_u64, _u32, _u32, _u32, _u32, _vp]),

@@ -118,6 +118,22 @@ int32_t ALACEncoder::EncodeBatch(const void *pcm, uint64_t totalSamples, uint32_
     return ALAC_noErr;
 }
 
+int32_t ALACEncoder::EncodeSegments(const void *pcm, const uint32_t *numSamples, uint32_t numPackets,
+                                    const uint32_t *segFirst, uint32_t numSegments, uint8_t *out, uint64_t outCapacity,
+                                    uint32_t *packetBytes, uint64_t *outTotalBytes)
+{
+    if (!mCtx) return kALAC_ParamError;
+    if (mFastMode) return kALAC_UnimplementedError;
+    alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
+    uint64_t total = 0;
+    mLastStatus = alac_hip_encode_host_segments(mCtx, &fmt, pcm, numSamples, numPackets, segFirst, numSegments, nullptr, 0,
+                                                out, outCapacity, packetBytes, &total);
+    if (mLastStatus != ALAC_HIP_noErr) return mLastStatus;
+    for (uint32_t p = 0; p < numPackets; p++) account(packetBytes[p]);
+    if (outTotalBytes) *outTotalBytes = total;
+    return ALAC_noErr;
+}
+
 // codec/ALACEncoder.cu:1385-1451
 void ALACEncoder::InitializeSampling(void *d_ip, AudioFormatDescription theInputFormat, int X, int32_t *outBytes)
 {

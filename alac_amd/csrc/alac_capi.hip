@@ -545,31 +545,26 @@ int32_t alac_hip_dyn_decomp(alac_hip_ctx *ctx, uint32_t mb0, uint32_t pb, uint32
 
 // ---- host-buffer convenience ---------------------------------------------------------------------
 
-int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *h_pcm,
-                             uint64_t total_samples, uint32_t segment_packets, int16_t *h_state, int32_t state_in,
-                             uint8_t *h_out, uint64_t out_capacity, uint32_t *h_packet_bytes,
-                             uint64_t *out_total_bytes)
+int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *h_pcm,
+                                      const uint32_t *h_num_samples, uint32_t num_packets, const uint32_t *h_seg_first,
+                                      uint32_t num_segments, int16_t *h_state, int32_t state_in, uint8_t *h_out,
+                                      uint64_t out_capacity, uint32_t *h_packet_bytes, uint64_t *out_total_bytes)
 {
     if (!ctx) return ALAC_HIP_ParamError;
     if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
     if (out_total_bytes) *out_total_bytes = 0;
-    if (total_samples == 0) return ALAC_HIP_noErr;
-    if (!h_pcm || !h_out || !h_packet_bytes) return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (num_packets == 0) return ALAC_HIP_noErr;
+    if (!h_pcm || !h_out || !h_packet_bytes || !h_num_samples || !h_seg_first || num_segments == 0)
+        return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (h_seg_first[0] != 0 || h_seg_first[num_segments] != num_packets)
+        return fail(ctx, ALAC_HIP_ParamError, "segment table must start at 0 and end at num_packets");
+    for (uint32_t s = 0; s < num_segments; s++)
+        if (h_seg_first[s] > h_seg_first[s + 1]) return fail(ctx, ALAC_HIP_ParamError, "segment table not ascending");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
 
     const uint32_t bpf = fmt->num_channels * bytes_per_sample(fmt->bit_depth);
-    const uint64_t np64 = (total_samples + fmt->frame_size - 1) / fmt->frame_size;
-    if (np64 > 0x7fffffffull) return fail(ctx, ALAC_HIP_ParamError, "too many packets");
-    const uint32_t np = (uint32_t)np64;
-    const uint32_t nseg = segment_packets ? (np + segment_packets - 1) / segment_packets : 1;
-    std::vector<uint32_t> ns(np, fmt->frame_size), segFirst(nseg + 1);
-    ns[np - 1] = (uint32_t)(total_samples - (uint64_t)(np - 1) * fmt->frame_size);
-    for (uint32_t s = 0; s <= nseg; s++) {
-        uint64_t f = segment_packets ? (uint64_t)s * segment_packets : (s ? np : 0);
-        segFirst[s] = (uint32_t)(f < np ? f : np);
-    }
-    const uint64_t pcmBytes = (uint64_t)np * fmt->frame_size * bpf;  // padded to whole packets
-    const uint64_t inBytes = total_samples * bpf;
+    const uint32_t np = num_packets, nseg = num_segments;
+    const uint64_t pcmBytes = (uint64_t)np * fmt->frame_size * bpf;
     const uint64_t wsBytes = alac_hip_encode_workspace_bytes(fmt, np, nseg);
     const uint64_t outMax = alac_hip_encode_max_output_bytes(fmt, np);
 
@@ -580,10 +575,9 @@ int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, cons
         (e = dSizes.alloc(np * 4ull)) || (e = dOffs.alloc((np + 1) * 8ull)))
         return fail(ctx, ALAC_HIP_MemFullError, "hipMalloc", e);
     hipStream_t st = ctx->stream;
-    if ((e = hipMemsetAsync(dPcm.p, 0, pcmBytes, st)) ||
-        (e = hipMemcpyAsync(dPcm.p, h_pcm, inBytes, hipMemcpyHostToDevice, st)) ||
-        (e = hipMemcpyAsync(dNs.p, ns.data(), np * 4ull, hipMemcpyHostToDevice, st)) ||
-        (e = hipMemcpyAsync(dSeg.p, segFirst.data(), (nseg + 1) * 4ull, hipMemcpyHostToDevice, st)))
+    if ((e = hipMemcpyAsync(dPcm.p, h_pcm, pcmBytes, hipMemcpyHostToDevice, st)) ||
+        (e = hipMemcpyAsync(dNs.p, h_num_samples, np * 4ull, hipMemcpyHostToDevice, st)) ||
+        (e = hipMemcpyAsync(dSeg.p, h_seg_first, (nseg + 1) * 4ull, hipMemcpyHostToDevice, st)))
         return fail(ctx, ALAC_HIP_ParamError, "H2D copy", e);
     if (h_state && state_in)
         if ((e = hipMemcpyAsync(dState.p, h_state, nseg * 128ull, hipMemcpyHostToDevice, st)))
@@ -606,6 +600,40 @@ int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, cons
     if ((e = hipStreamSynchronize(st))) return fail(ctx, ALAC_HIP_ParamError, "sync", e);
     if (out_total_bytes) *out_total_bytes = total;
     return ALAC_HIP_noErr;
+}
+
+int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *h_pcm,
+                             uint64_t total_samples, uint32_t segment_packets, int16_t *h_state, int32_t state_in,
+                             uint8_t *h_out, uint64_t out_capacity, uint32_t *h_packet_bytes,
+                             uint64_t *out_total_bytes)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
+    if (out_total_bytes) *out_total_bytes = 0;
+    if (total_samples == 0) return ALAC_HIP_noErr;
+    if (!h_pcm || !h_out || !h_packet_bytes) return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    const uint32_t bpf = fmt->num_channels * bytes_per_sample(fmt->bit_depth);
+    const uint64_t np64 = (total_samples + fmt->frame_size - 1) / fmt->frame_size;
+    if (np64 > 0x7fffffffull) return fail(ctx, ALAC_HIP_ParamError, "too many packets");
+    const uint32_t np = (uint32_t)np64;
+    const uint32_t nseg = segment_packets ? (np + segment_packets - 1) / segment_packets : 1;
+    std::vector<uint32_t> ns(np, fmt->frame_size), segFirst(nseg + 1);
+    ns[np - 1] = (uint32_t)(total_samples - (uint64_t)(np - 1) * fmt->frame_size);
+    for (uint32_t s = 0; s <= nseg; s++) {
+        uint64_t f = segment_packets ? (uint64_t)s * segment_packets : (s ? np : 0);
+        segFirst[s] = (uint32_t)(f < np ? f : np);
+    }
+    // the last packet may be partial: hand over whole packets (zero padded)
+    const uint64_t inBytes = total_samples * bpf, pcmBytes = (uint64_t)np * fmt->frame_size * bpf;
+    const void *src = h_pcm;
+    std::vector<uint8_t> padded;
+    if (inBytes != pcmBytes) {
+        padded.assign(pcmBytes, 0);
+        memcpy(padded.data(), h_pcm, inBytes);
+        src = padded.data();
+    }
+    return alac_hip_encode_host_segments(ctx, fmt, src, ns.data(), np, segFirst.data(), nseg, h_state, state_in, h_out,
+                                         out_capacity, h_packet_bytes, out_total_bytes);
 }
 
 int32_t alac_hip_decode_host(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size,

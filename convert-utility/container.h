@@ -1,0 +1,79 @@
+/*
+ * container.h — WAV / CAF reading and writing for alacconvert, in-memory (a file is a byte vector).
+ *
+ * Reproduces byte for byte what the reference's convert utility writes and accepts what it accepts:
+ * convert-utility/main.cu:196-385 (format sniffing, data-chunk search), :387-643 (EncodeALAC file layout),
+ * :646-790 (DecodeALAC), :803-852 (WAVE header), and convert-utility/CAFFileALAC.cpp:25-456 (chunk writers,
+ * BER integers, packet-table header, chunk scanning).  The reference walks FILE*s with fseek/ftell; here the
+ * layout is computed once and emitted in order, which gives the same bytes without any seeking.
+ */
+#ifndef ALACCONVERT_CONTAINER_H
+#define ALACCONVERT_CONTAINER_H
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace alacfile {
+
+typedef std::vector<uint8_t> Bytes;
+
+enum FileKind { kUnknownFile = 0, kWaveFile, kCafFile };
+
+/* what the sniffers learn about an input file (main.cu:196-385, CAFFileALAC.cpp:395-456) */
+struct InputInfo {
+    FileKind kind;
+    bool isAlac;          /* 'alac' (decode) vs 'lpcm' (encode) */
+    bool bigEndianPcm;    /* CAF lpcm without the little-endian flag: samples are swapped on the way in */
+    double sampleRate;
+    uint32_t channels;
+    uint32_t bitsPerChannel;   /* lpcm: sample width; alac: 0 */
+    uint32_t alacSourceFlag;   /* alac: 1..4 = 16/20/24/32-bit source (desc.mFormatFlags) */
+    uint32_t framesPerPacket;
+    uint64_t dataPos;          /* first payload byte (past the CAF edit count) */
+    uint64_t dataSize;         /* payload bytes, clamped to what the file really holds */
+};
+
+/* returns an empty string on success, else the reference's diagnostic text */
+std::string sniff_input(const Bytes &file, InputInfo &info);
+
+/* ---- BER-style variable length integers of the CAF packet table (CAFFileALAC.cpp:189-260) ---- */
+void append_ber(Bytes &out, uint32_t value);
+/* reads one integer from p[0..avail); *used = bytes consumed (0 on malformed input) */
+uint32_t read_ber(const uint8_t *p, size_t avail, size_t *used);
+
+/* ---- ALAC in CAF (encode side) ---- */
+struct AlacCafParams {
+    double sampleRate;
+    uint32_t channels;
+    uint32_t bitDepth;          /* 16 / 20 / 24 / 32 */
+    uint32_t framesPerPacket;   /* 4096 */
+    uint64_t inputDataBytes;    /* PCM payload size the packet-table header is derived from (BuildBasePacketTable) */
+};
+/* caff + desc + kuki (+ chan) + pakt (+ free) + data, exactly as main.cu:387-643 leaves the file */
+Bytes build_alac_caf(const AlacCafParams &p, const Bytes &cookie, const std::vector<uint32_t> &packetBytes,
+                     const uint8_t *stream, uint64_t streamBytes);
+
+/* ---- ALAC in CAF (decode side) ---- */
+struct AlacCafContents {
+    Bytes cookie;
+    std::vector<uint32_t> packetBytes;   /* packets the reference's read loop would decode (main.cu:719-737) */
+    uint64_t dataPos;
+};
+std::string parse_alac_caf(const Bytes &file, const InputInfo &info, AlacCafContents &out);
+
+/* ---- PCM out (decode side) ---- */
+Bytes build_wave(double sampleRate, uint32_t channels, uint32_t bitsPerChannel, const uint8_t *pcm, uint64_t pcmBytes);
+Bytes build_pcm_caf(double sampleRate, uint32_t channels, uint32_t bitsPerChannel, const uint8_t *pcm, uint64_t pcmBytes);
+
+/* byte order of CAF big-endian lpcm -> packed little-endian (main.cu:482-507) */
+void swap_samples_in_place(uint8_t *pcm, uint64_t bytes, uint32_t bitsPerChannel);
+
+/* file helpers */
+bool read_file(const std::string &path, Bytes &out);
+bool write_file(const std::string &path, const Bytes &data);
+bool has_wav_extension(const std::string &path);   /* main.cu:792-808 */
+
+}  // namespace alacfile
+
+#endif

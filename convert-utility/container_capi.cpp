@@ -1,0 +1,107 @@
+/*
+ * container_capi.cpp — C entry points over container.cpp so that the CPU-side tests can drive the container
+ * code through ctypes without a GPU (tests/test_container.py).  Not part of the product binary.
+ */
+#include <cstring>
+
+#include "container.h"
+
+using namespace alacfile;
+
+extern "C" {
+
+struct alacfile_info {
+    int32_t kind, is_alac, big_endian_pcm;
+    double sample_rate;
+    uint32_t channels, bits_per_channel, alac_source_flag, frames_per_packet;
+    uint64_t data_pos, data_size;
+};
+
+/* returns 0 on success, -1 with the diagnostic in err[errcap] */
+int32_t alacfile_sniff(const uint8_t *file, uint64_t size, alacfile_info *out, char *err, uint32_t errcap)
+{
+    Bytes f(file, file + size);
+    InputInfo info;
+    const std::string e = sniff_input(f, info);
+    if (err && errcap) {
+        strncpy(err, e.c_str(), errcap - 1);
+        err[errcap - 1] = 0;
+    }
+    out->kind = info.kind;
+    out->is_alac = info.isAlac;
+    out->big_endian_pcm = info.bigEndianPcm;
+    out->sample_rate = info.sampleRate;
+    out->channels = info.channels;
+    out->bits_per_channel = info.bitsPerChannel;
+    out->alac_source_flag = info.alacSourceFlag;
+    out->frames_per_packet = info.framesPerPacket;
+    out->data_pos = info.dataPos;
+    out->data_size = info.dataSize;
+    return e.empty() ? 0 : -1;
+}
+
+static uint64_t give(const Bytes &b, uint8_t *out, uint64_t cap)
+{
+    if (out && b.size() <= cap) memcpy(out, b.data(), b.size());
+    return b.size();
+}
+
+/* each builder returns the size of the file image; it is copied to out when it fits in cap */
+uint64_t alacfile_build_alac_caf(double sample_rate, uint32_t channels, uint32_t bit_depth, uint32_t frames_per_packet,
+                                 uint64_t input_data_bytes, const uint8_t *cookie, uint32_t cookie_size,
+                                 const uint32_t *packet_bytes, uint32_t num_packets, const uint8_t *stream,
+                                 uint64_t stream_bytes, uint8_t *out, uint64_t cap)
+{
+    AlacCafParams p = {sample_rate, channels, bit_depth, frames_per_packet, input_data_bytes};
+    Bytes ck(cookie, cookie + cookie_size);
+    std::vector<uint32_t> sizes(packet_bytes, packet_bytes + num_packets);
+    return give(build_alac_caf(p, ck, sizes, stream, stream_bytes), out, cap);
+}
+
+uint64_t alacfile_build_wave(double sample_rate, uint32_t channels, uint32_t bits, const uint8_t *pcm, uint64_t pcm_bytes,
+                             uint8_t *out, uint64_t cap)
+{
+    return give(build_wave(sample_rate, channels, bits, pcm, pcm_bytes), out, cap);
+}
+
+uint64_t alacfile_build_pcm_caf(double sample_rate, uint32_t channels, uint32_t bits, const uint8_t *pcm, uint64_t pcm_bytes,
+                                uint8_t *out, uint64_t cap)
+{
+    return give(build_pcm_caf(sample_rate, channels, bits, pcm, pcm_bytes), out, cap);
+}
+
+/* cookie to cookie_out (cap 64), packet sizes to sizes_out (cap max_packets); returns the packet count or -1 */
+int64_t alacfile_parse_alac_caf(const uint8_t *file, uint64_t size, uint8_t *cookie_out, uint32_t *cookie_size,
+                                uint32_t *sizes_out, uint32_t max_packets, uint64_t *data_pos)
+{
+    Bytes f(file, file + size);
+    InputInfo info;
+    if (!sniff_input(f, info).empty() || !info.isAlac) return -1;
+    AlacCafContents c;
+    if (!parse_alac_caf(f, info, c).empty()) return -1;
+    *cookie_size = (uint32_t)c.cookie.size();
+    if (c.cookie.size() <= 64) memcpy(cookie_out, c.cookie.data(), c.cookie.size());
+    for (size_t i = 0; i < c.packetBytes.size() && i < max_packets; i++) sizes_out[i] = c.packetBytes[i];
+    *data_pos = c.dataPos;
+    return (int64_t)c.packetBytes.size();
+}
+
+void alacfile_swap_samples(uint8_t *pcm, uint64_t bytes, uint32_t bits) { swap_samples_in_place(pcm, bytes, bits); }
+
+uint32_t alacfile_append_ber(uint32_t value, uint8_t *out5)
+{
+    Bytes b;
+    append_ber(b, value);
+    memcpy(out5, b.data(), b.size());
+    return (uint32_t)b.size();
+}
+
+uint32_t alacfile_read_ber(const uint8_t *p, uint32_t avail, uint32_t *used)
+{
+    size_t u = 0;
+    const uint32_t v = read_ber(p, avail, &u);
+    *used = (uint32_t)u;
+    return v;
+}
+
+}  // extern "C"

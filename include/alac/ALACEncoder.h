@@ -45,6 +45,13 @@ public:
     int32_t EncodeBatch(const void *pcm, uint64_t totalSamples, uint32_t segmentPackets, uint8_t *out,
                         uint64_t outCapacity, uint32_t *packetBytes, uint64_t *outTotalBytes);
 
+    /* Multi-stream form: packets back to back at the full-packet stride (frameSize * bytesPerFrame), packet p
+     * holding numSamples[p] frames; segment s = packets [segFirst[s], segFirst[s+1]) is one independent stream
+     * (one input file) starting from the initial coefficient state. */
+    int32_t EncodeSegments(const void *pcm, const uint32_t *numSamples, uint32_t numPackets, const uint32_t *segFirst,
+                           uint32_t numSegments, uint8_t *out, uint64_t outCapacity, uint32_t *packetBytes,
+                           uint64_t *outTotalBytes);
+
     int32_t LastStatus() const { return mLastStatus; }
 
 protected:

@@ -168,6 +168,14 @@ int32_t alac_hip_encode_host(alac_hip_ctx *ctx, const alac_hip_format *fmt, cons
                              uint64_t total_samples, uint32_t segment_packets, int16_t *h_state,
                              int32_t state_in, uint8_t *h_out, uint64_t out_capacity,
                              uint32_t *h_packet_bytes, uint64_t *out_total_bytes);
+/* General form: packets back to back at the full-packet stride, packet p holding h_num_samples[p] frames;
+ * segment s = packets [h_seg_first[s], h_seg_first[s+1]) chained through the coefficient state (one
+ * segment per input file in a multi-file conversion).  h_state: num_segments * 64 int16, may be NULL. */
+int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *h_pcm,
+                                      const uint32_t *h_num_samples, uint32_t num_packets,
+                                      const uint32_t *h_seg_first, uint32_t num_segments, int16_t *h_state,
+                                      int32_t state_in, uint8_t *h_out, uint64_t out_capacity,
+                                      uint32_t *h_packet_bytes, uint64_t *out_total_bytes);
 int32_t alac_hip_decode_host(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size,
                              const uint8_t *h_stream, const uint32_t *h_packet_bytes,
                              uint32_t num_packets, uint8_t *h_pcm_out, uint32_t *h_num_samples_out,

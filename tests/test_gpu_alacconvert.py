@@ -1,0 +1,131 @@
+"""alacconvert (convert-utility/) on the GPU: files written by the product binary are byte-identical to what the
+procedural oracle (oracle/caf_oracle.py over the C oracle codec) says the reference leaves on disk."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import caf_oracle as co  # noqa: E402
+from container_lib import music_like  # noqa: E402
+from test_container import oracle_codec  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+CU = os.path.join(ROOT, "convert-utility")
+BIN = os.path.join(CU, "alacconvert")
+
+
+@pytest.fixture(scope="module")
+def binary(gpu_ctx):
+    subprocess.check_call(["make", "-C", CU, "alacconvert"], stdout=subprocess.DEVNULL)
+    return BIN
+
+
+def run(binary, *args):
+    p = subprocess.run([binary] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    return p.returncode, p.stdout, p.stderr
+
+
+def oracle_encode(oracle, data, bits, ch, rate):
+    cookie, enc, dec = oracle_codec(oracle, bits, ch, rate)
+    return co.encode_file(data, cookie, enc), dec
+
+
+def golden_pcm(name):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "packets.npz"))
+    return z[name].tobytes()
+
+
+@pytest.mark.parametrize("case", ["stereo16_music", "mono16_music", "stereo24", "stereo32", "stereo16_exact", "tiny"])
+def test_single_file_round_trip_is_reference_identical(binary, oracle, tmp_path, case):
+    if case == "stereo16_music":
+        bits, ch, pcm = 16, 2, golden_pcm("stereo_pcm")          # excerpt of the reference's audio/50.wav
+    elif case == "mono16_music":
+        bits, ch, pcm = 16, 1, golden_pcm("mono_pcm")
+    elif case == "stereo24":
+        bits, ch, pcm = 24, 2, music_like(4096 * 2 + 77, 2, 24, 3)
+    elif case == "stereo32":
+        bits, ch, pcm = 32, 2, music_like(4096 + 5, 2, 32, 4)
+    elif case == "stereo16_exact":
+        bits, ch, pcm = 16, 2, music_like(4096 * 3, 2, 16, 5)    # phantom packet in the table header
+    else:
+        bits, ch, pcm = 16, 2, music_like(40, 2, 16, 6)
+    wav = co.make_wav(pcm, ch, 44100, bits, extra_chunks=[(b"LIST", b"infoinfo")])
+    src, caf, back = tmp_path / "in.wav", tmp_path / "out.caf", tmp_path / "back.wav"
+    src.write_bytes(wav)
+    rc, out, err = run(binary, src, caf)
+    assert rc == 0, err
+    assert out == f"Input file: {src}\nOutput file: {caf}\n"
+    want, dec = oracle_encode(oracle, wav, bits, ch, 44100)
+    got = caf.read_bytes()
+    assert got == want
+    rc, _, err = run(binary, caf, back)
+    assert rc == 0, err
+    assert back.read_bytes() == co.decode_file(want, True, dec)
+    assert back.read_bytes()[44:] == pcm
+    # CAF PCM out as well (any extension but .wav), and that file is a valid encode input again
+    back_caf = tmp_path / "back.caf"
+    assert run(binary, caf, back_caf)[0] == 0
+    assert back_caf.read_bytes() == co.decode_file(want, False, dec)
+    again = tmp_path / "again.caf"
+    assert run(binary, back_caf, again)[0] == 0
+    assert again.read_bytes() == want
+
+
+def test_batch_outputs_equal_single_file_outputs(binary, oracle, tmp_path):
+    specs = [(16, 2, 4096 * 4 + 100, 11), (16, 2, 4096 * 2, 12), (16, 1, 5000, 13), (24, 2, 4096 + 9, 14), (16, 2, 7, 15),
+             (16, 2, 4096 * 7 + 1, 16)]
+    args, wants = ["--batch"], []
+    for i, (bits, ch, frames, seed) in enumerate(specs):
+        pcm = music_like(frames, ch, bits, seed)
+        wav = co.make_wav(pcm, ch, 48000 if i == 1 else 44100, bits)
+        src, dst = tmp_path / f"in{i}.wav", tmp_path / f"out{i}.caf"
+        src.write_bytes(wav)
+        args += [src, dst]
+        wants.append((dst, oracle_encode(oracle, wav, bits, ch, 48000 if i == 1 else 44100)[0], pcm))
+    rc, _, err = run(binary, *args)
+    assert rc == 0, err
+    for dst, want, _ in wants:
+        assert dst.read_bytes() == want
+    # and the whole batch decodes in one call too
+    args = ["--batch"]
+    for i, (dst, _, _) in enumerate(wants):
+        args += [dst, tmp_path / f"back{i}.wav"]
+    rc, _, err = run(binary, *args)
+    assert rc == 0, err
+    for i, (_, _, pcm) in enumerate(wants):
+        assert (tmp_path / f"back{i}.wav").read_bytes()[44:] == pcm
+
+
+def test_segment_mode_is_valid_alac_and_decodes_to_the_input(binary, oracle, tmp_path):
+    bits, ch = 16, 2
+    pcm = music_like(4096 * 6 + 300, ch, bits, 21)
+    wav = co.make_wav(pcm, ch, 44100, bits)
+    src, caf = tmp_path / "in.wav", tmp_path / "seg.caf"
+    src.write_bytes(wav)
+    rc, _, err = run(binary, "--segment-packets", 2, src, caf)
+    assert rc == 0, err
+    cookie, _, dec = oracle_codec(oracle, bits, ch, 44100)
+    got = caf.read_bytes()
+    assert co.decode_file(got, True, dec)[44:] == pcm       # any ALAC decoder accepts it
+    # segments of 2 packets: packets 0-1 equal the chained encode, the stream as a whole does not
+    enc = oracle.encoder(4096, bits, ch, 44100)
+    stream, sizes = enc.encode_stream(np.frombuffer(pcm, np.uint8), len(pcm) // 4, segment_packets=2)
+    dpos = got.index(b"data") + 16
+    assert got[dpos:dpos + len(stream)] == stream.tobytes()
+
+
+def test_bad_invocations(binary, tmp_path):
+    assert run(binary)[0] == 1
+    rc, out, _ = run(binary, "-x", "a", "b")
+    assert rc == 1 and out.startswith("unknown option: -x\n")
+    rc, _, err = run(binary, tmp_path / "missing.wav", tmp_path / "o.caf")
+    assert rc == 1 and "Cannot open file" in err
+    junk = tmp_path / "junk.wav"
+    junk.write_bytes(b"not a wave file at all")
+    rc, _, err = run(binary, junk, tmp_path / "o.caf")
+    assert rc == 1 and "Cannot determine what format" in err
