@@ -80,13 +80,14 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.pred = off;
     off = align_up(off + (uint64_t)(f->frame_size / 8 + 1) * lanes * 4, 256);
     L.chainsPad = (uint32_t)lanes;
-    const uint64_t n8 = f->frame_size / 8 + 1;
+    // +16 rows: the coder waves read whole 16-row blocks up to the wave's longest chain
+    const uint64_t n8 = f->frame_size / 8 + 1 + 16;
     L.resA = off;
     off = align_up(off + (f->num_channels == 2 ? n8 * 5 * lanes * 4 : 0), 256);
     L.resB = off;
     off = align_up(off + n8 * 2 * lanes * 4, 256);
     L.resC = off;
-    off = align_up(off + (uint64_t)f->frame_size * lanes * 4, 256);
+    off = align_up(off + ((uint64_t)f->frame_size + 16) * lanes * 4, 256);
     L.bits1 = off;
     off = align_up(off + 5 * lanes * 4, 256);
     L.cost2 = off;

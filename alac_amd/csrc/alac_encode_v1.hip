@@ -527,11 +527,11 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
     uint32_t p, N;
     const bool active = seg_packet(A.S, chain / CH, p, N);
     const uint32_t n8 = active ? N / 8 : 0;
-    const int32_t *src = A.resA + (uint64_t)r * A.chainsPad + chain;
+    const int32_t *plane = A.resA + (uint64_t)r * A.chainsPad;
     const uint64_t stride = 5ull * A.chainsPad;
     GolF g;
     golf_reset(g);
-    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return src[j * stride]; });
+    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; });
     if (active) A.bits1[t] = g.bits;
 }
 
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         uint32_t p, N;
         const bool active = seg_packet(A.S, chain >> 1, p, N);
         const uint32_t n8 = active ? N / 8 : 0;
-        const int32_t *src = A.resA + (uint64_t)r * A.chainsPad + chain;
+        const int32_t *plane = A.resA + (uint64_t)r * A.chainsPad;
         const uint64_t stride = 5ull * A.chainsPad;
         GolF g;
         golf_reset(g);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = r << 16;
-        golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return src[j * stride]; }, wait);
+        golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; }, wait);
         if (active) A.bits1[t] = g.bits;
     }
 }
@@ -620,14 +620,20 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
         P2 = n32 > na + 1 ? n32 : na + 1;
         P2 = P2 < n8 ? P2 : n8;
     }
-    const int32_t *srcB = A.resB + (uint64_t)rs * A.chainsPad + chain;
-    const uint64_t strideB = 2ull * A.chainsPad;
-    const int32_t *srcA = A.resA + (uint64_t)kMaxRes * A.chainsPad + chain;
-    const uint64_t strideA = 5ull * A.chainsPad;
+    const uint64_t strideB = 2ull * A.chainsPad, strideA = 5ull * A.chainsPad;
     GolF g;
     golf_reset(g);
-    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip,
-                       [&](uint32_t j) { return j < P2 ? srcB[j * strideB] : srcA[j * strideA]; });
+    // both planes are read for every row (uniform addresses, no branch); the lane's P2 picks the value
+    const int32_t *planeB = A.resB + (uint64_t)rs * A.chainsPad, *planeA = A.resA + (uint64_t)kMaxRes * A.chainsPad;
+    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) {
+        const int32_t b = (planeB + j * strideB)[chain];
+        if constexpr (CH == 2) {
+            const int32_t a = (planeA + j * strideA)[chain];
+            return j < P2 ? b : a;
+        } else {
+            return b;
+        }
+    });
     if (active) A.cost2[t] = g.bits * 8 + 16 * na;  // :438, :447 / :899
 }
 
@@ -677,13 +683,13 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     if (active && rec->escape) active = false;
     const uint32_t c = chain % CH;
     const uint32_t n = active ? N : 0;
-    const int32_t *src = A.resC + chain;
+    const int32_t *plane = A.resC;
     const uint64_t stride = A.chainsPad;
     GolF g;
     golf_reset(g);
     g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
-    g.wcap = A.wcap;
-    golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return src[j * stride]; });
+    g.wleft = A.wcap - 1;
+    golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; });
     golf_flush<true>(g);
     if (active) rec->c[c].bits = g.bits;
 }
@@ -733,18 +739,18 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         if (active && rec->escape) active = false;
         const uint32_t c = chain % CH;
         const uint32_t n = active ? N : 0;
-        const int32_t *src = A.resC + chain;
+        const int32_t *plane = A.resC;
         const uint64_t stride = A.chainsPad;
         GolF g;
         golf_reset(g);
         g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
-        g.wcap = A.wcap;
+        g.wleft = A.wcap - 1;
         RowWait wait;
         wait.f0 = A.flags + 2 * w;
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = 0;
-        golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return src[j * stride]; }, wait);
+        golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; }, wait);
         golf_flush<true>(g);
         if (active) rec->c[c].bits = g.bits;
     }

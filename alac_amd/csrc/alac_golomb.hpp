@@ -25,9 +25,9 @@ __device__ __forceinline__ void gol_table_init(uint32_t *recip, int tid)
 
 struct GolF {
     uint32_t mb, zmode, inrun, nz, bits;
-    uint64_t acc;
-    uint32_t nacc, widx, wcap;
-    uint32_t *wp;
+    uint64_t acc;      // the most recent bits, right aligned; the low `nacc` of them are not yet a full word
+    uint32_t nacc, wleft;
+    uint32_t *wp;      // where the word being assembled goes
 };
 
 __device__ __forceinline__ void golf_reset(GolF &g)
@@ -39,11 +39,14 @@ __device__ __forceinline__ void golf_reset(GolF &g)
     g.bits = 0;
     g.acc = 0;
     g.nacc = 0;
-    g.widx = 0;
-    g.wcap = 0;
+    g.wleft = 0;
     g.wp = nullptr;
 }
 
+// Append the low `nbits` (<= 32) of value.  The word under assembly is stored EVERY time (left aligned; a later
+// put completes it in place) and the pointer advances when it fills up:
+// no branch, no exec juggling — a lone wave pays ~16-24 cycles per branch, more than the redundant store.
+// Only lanes that own a valid `wp` may call this (the callers sit inside the active-lane regions).
 template <bool WRITE>
 __device__ __forceinline__ void golf_put(GolF &g, uint32_t value, uint32_t nbits)
 {
@@ -51,23 +54,20 @@ __device__ __forceinline__ void golf_put(GolF &g, uint32_t value, uint32_t nbits
     if constexpr (WRITE) {
         g.acc = (g.acc << nbits) | (uint64_t)value;  // callers hand in values already confined to nbits
         g.nacc += nbits;
-        if (g.nacc >= 32) {
-            g.nacc -= 32;
-            if (g.widx < g.wcap) g.wp[g.widx] = (uint32_t)(g.acc >> g.nacc);
-            g.widx++;
-        }
+        *g.wp = (uint32_t)((g.acc << ((64u - g.nacc) & 63u)) >> 32);
+        const uint32_t adv = min(g.nacc >> 5, g.wleft);  // capacity reached: stay (the packet escapes anyway)
+        g.wleft -= adv;
+        g.wp += adv;
+        g.nacc &= 31u;
     }
 }
 
+// the bits left over after the last full word (golf_put stores before it advances)
 template <bool WRITE>
 __device__ __forceinline__ void golf_flush(GolF &g)
 {
     if constexpr (WRITE) {
-        if (g.nacc > 0) {
-            if (g.widx < g.wcap) g.wp[g.widx] = (uint32_t)(g.acc << (32 - g.nacc));
-            g.widx++;
-            g.nacc = 0;
-        }
+        if (g.nacc > 0) *g.wp = (uint32_t)((g.acc << (64u - g.nacc)) >> 32);
     }
 }
 
@@ -94,21 +94,24 @@ __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
     g.inrun = 0;
 }
 
-// one residual; `valid` = this lane still has samples, `last` = final sample of its block.
+// one residual.  CHECKED: `valid` = this lane still has samples (only needed in blocks where some lane of the
+// wave has run out).  The end of the stream is NOT handled here: a run still open after the last residual is
+// closed by golf_finish, and a run "entered" by the last residual is dropped there (ag_enc.c:328 enters zero
+// mode only when c < numSamples).
 // Control flow is kept to three short regions so that a wave whose lanes are in different coder states
 // (zero run / normal / escape) does not execute long divergent bodies: (A) run bookkeeping, (B) run close,
-// entered only when some lane closes a run, (C) the symbol itself with the escape handled by selects.
+// entered only when some lane closes a run, (C) the symbol itself, straight-line (escape handled by selects).
 // Requires bitSize <= 23 so that the escape (9 ones + bitSize raw bits) is one <= 32-bit put.
-template <bool WRITE>
-__device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, bool last, uint32_t bitSize,
-                                         const uint32_t *recip)
+template <bool WRITE, bool CHECKED>
+__device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint32_t bitSize, const uint32_t *recip)
 {
+    if constexpr (!CHECKED) valid = true;
     // (A) ag_enc.c:333-349
     const bool inrun = valid && g.inrun;
     const bool swallow = inrun && (del == 0);
     g.nz += swallow ? 1u : 0u;
     const bool cap = swallow && (g.nz >= 65535);
-    const bool close = inrun && (!swallow || cap || last);
+    const bool close = inrun && (!swallow || cap);
     // (B)
     if (__any(close)) {
         if (close) {
@@ -118,35 +121,38 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, bool 
     }
     // (C) ag_enc.c:285-331
     if (valid && !swallow) {
-        const uint32_t k = min((uint32_t)lg3a(g.mb >> kQBShift), kKB0);
+        // k = min(lg3a(mb >> 9), kb); lg3a(x) = 31 - clz(x + 3) and clz((mb >> 9) + 3) = clz(mb + 1536) + 9
+        const uint32_t k = min(22u - (uint32_t)__builtin_clz(g.mb + (3u << kQBShift)), kKB0);
         const uint32_t m = (1u << k) - 1;
-        const uint32_t a = (uint32_t)(del < 0 ? -del : del);
-        const uint32_t t2 = (a << 1) - ((uint32_t)del >> 31);  // n + zmode
+        // n + zmode = 2|del| - (del < 0): the zig-zag map
+        const uint32_t t2 = ((uint32_t)del << 1) ^ (uint32_t)(del >> 31);
         const uint32_t n = t2 - g.zmode;
         const bool esc = n >= m * 9;  // div >= MAX_PREFIX_32
-        // n / m for m = 2^k - 1, needed only when n < 9 m (else escape).  n = q0 * 2^k + r0 = q0 * m + (q0 + r0)
-        // with q0 <= 8, so for m >= 15 the quotient is q0 or q0 + 1; the three small moduli (1, 3, 7; n < 63)
-        // use an 8-bit reciprocal (256, 86, 37: exact on that range).  No table, no division.
+        // n / m for m = 2^k - 1, needed only when n < 9 m.  With n = q0 2^k + r0 = q0 m + (q0 + r0) and
+        // t0 = q0 + r0 = q1 2^k + r1 = q1 m + (q1 + r1): n / m = q0 + q1 + [q1 + r1 >= m] for every k >= 2
+        // (q0 <= 8 keeps q1 + r1 < 2 m); m = 1 is the identity.  No table, no division.
         const uint32_t q0 = n >> k;
         const uint32_t t0 = q0 + (n & m);
-        const uint32_t divA = q0 + (t0 >= m ? 1u : 0u);
-        const uint32_t c8 = k == 1 ? 256u : (k == 2 ? 86u : 37u);
-        const uint32_t divB = __umul24(n & 0xffu, c8) >> 8;
-        const uint32_t div = k >= 4 ? divA : divB;
+        const uint32_t q1 = t0 >> k;
+        const uint32_t t1 = q1 + (t0 & m);
+        uint32_t div = q0 + q1 + (t1 >= m ? 1u : 0u);
+        div = k == 1 ? n : div;
         const uint32_t mod = n - __umul24(div, m);
-        const uint32_t de = (mod == 0);
-        uint32_t numBits = div + k + 1 - de;
-        uint32_t value = (((1u << div) - 1) << (numBits - div)) + mod + 1 - de;
+        // dyn_code_32bit (:151-183): numBits = div + k + 1 - [mod == 0], value = ones(div) 0 (mod + 1 - [mod == 0])
+        const uint32_t ne = min(mod, 1u);
+        const uint32_t kd = k + ne;
+        uint32_t numBits = div + kd;
+        uint32_t value = (((1u << div) - 1) << kd) + mod + ne;
         if (esc) {
             numBits = kMaxPrefix + bitSize;
             value = (((1u << kMaxPrefix) - 1) << bitSize) | (n & ((1u << bitSize) - 1));
         }
         golf_put<WRITE>(g, value, numBits);
         // mb = pb * (n + zmode) + mb - ((pb * mb) >> 9), pb = 40   (:318)
-        const uint32_t pm = (g.mb << 5) + (g.mb << 3);
-        uint32_t mb = (t2 << 5) + (t2 << 3) + g.mb - (pm >> kQBShift);
+        // (mb can pass 2^24 under sustained large residuals: shifts, not a 24-bit multiply; t2 < 2^24 always)
+        uint32_t mb = __umul24(t2, 40u) + g.mb - (((g.mb << 5) + (g.mb << 3)) >> kQBShift);
         mb = n > kMeanClamp ? kMeanClamp : mb;
-        const bool enter = (mb < (1u << (kQBShift - 2))) && !last;  // (mb << 2) < QB, :328
+        const bool enter = mb < (1u << (kQBShift - 2));  // (mb << 2) < QB, :328
         g.mb = mb;
         g.zmode = enter ? 1u : 0u;
         g.inrun = enter ? 1u : 0u;
@@ -154,12 +160,33 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, bool 
     }
 }
 
-// Walk one stream of `n` residuals laid out with `stride` (the [sample][stream] planes).  Three 16-sample
-// register buffers rotate so that a block's loads are issued two blocks (32 symbols) before it is coded:
-// the bit-word stores of the coder share the vector-memory counter with the loads, so the compiler can only
-// wait for "everything outstanding" (vmcnt(0)) — with two blocks of distance that wait finds the loads done.
+// after the last residual: a run that swallowed zeros up to the end is coded now (:351); one that was only
+// just entered by the last residual does not exist in the reference (:328, c < numSamples) and is dropped
+template <bool WRITE>
+__device__ __forceinline__ void golf_finish(GolF &g, bool active, const uint32_t *recip)
+{
+    const bool close = active && g.inrun && g.nz > 0;
+    if (__any(close)) {
+        if (close) golf_close_run<WRITE>(g, recip);
+    }
+    g.inrun = 0;
+}
+
+// Walk one stream of `n` residuals.  `fetch(j)` returns this lane's residual of row j, with j WAVE-UNIFORM: every
+// lane loads every row up to the wave's longest stream (rows beyond a lane's own length are ignored, never
+// branched around), so the address is a scalar row base plus the lane's column.  Three 16-sample register
+// buffers rotate so that a block's loads are issued two blocks (32 symbols) before it is coded: the bit-word
+// stores of the coder share the vector-memory counter with the loads, so the compiler can only wait for
+// "everything outstanding" (vmcnt(0)) — with two blocks of distance that wait finds the loads done.
 // `need(rows)` is called (wave-uniformly) before rows < `rows` of the plane are read: a no-op when the plane was
 // written by an earlier kernel, a flag wait + acquire when a producer in the same launch is still writing it.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 struct NoWait {
     __device__ __forceinline__ void operator()(uint32_t) const {}
 };
@@ -171,16 +198,21 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
     constexpr int B = 16;
     int32_t bufA[B], bufB[B], bufC[B];
     auto load = [&](int32_t (&buf)[B], uint32_t jb) {
-        if (jb < nMaxWave) need(min(jb + B, nMaxWave));
+        if (jb < nMaxWave) {
+            need(min(jb + B, nMaxWave));
 #pragma unroll
-        for (int s = 0; s < B; s++) buf[s] = (jb + s) < n ? fetch(jb + s) : 0;
+            for (int s = 0; s < B; s++) buf[s] = fetch(jb + s);
+        }
     };
+    const uint32_t nMinWave = wave_min_u32(n);
     auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
         if (jb >= nMaxWave) return;
+        if (jb + B <= nMinWave) {  // every lane owns the whole block
 #pragma unroll
-        for (int s = 0; s < B; s++) {
-            const uint32_t j = jb + s;
-            golf_sym<WRITE>(g, buf[s], j < n, j + 1 == n, bitSize, recip);
+            for (int s = 0; s < B; s++) golf_sym<WRITE, false>(g, buf[s], true, bitSize, recip);
+        } else {
+#pragma unroll
+            for (int s = 0; s < B; s++) golf_sym<WRITE, true>(g, buf[s], jb + s < n, bitSize, recip);
         }
     };
     load(bufA, 0);
@@ -193,6 +225,7 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
         load(bufB, jb + 4 * B);
         code(bufC, jb + 2 * B);
     }
+    golf_finish<WRITE>(g, n > 0, recip);
 }
 
 }  // namespace alacdev
