@@ -239,6 +239,79 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
     }
 }
 
+// ---- interior fast path of the staging (16-bit PCM, tile and its history fully inside every packet of the
+// wave): everything that does not change from tile to tile is computed once per pass, and a tile costs one
+// 16-byte (stereo) / 8-byte (mono) load plus the mix and the LDS writes per task — no bounds checks, no branches.
+template <int CH, int LPC>
+struct StagePlan {
+    static constexpr int ITERS = StageRegs<CH, LPC>::ITERS;
+    const uint8_t *pk[ITERS];  // address of the task's 4 sample-frames when the tile starts at j0 = kHist
+    int xs[ITERS];             // LDS cell of the task's first u (v follows one row further)
+    int32_t wl[ITERS], wr[ITERS], vsel[ITERS];  // u = (wl l + wr r) >> 2; v = vsel ? l - r : r
+    bool usable;               // 16-bit, vector-aligned frames
+};
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShared<LPC> &sh, const uint8_t *pcm,
+                                           uint32_t frameBytes, int lane)
+{
+    constexpr int GROUPS = kRowLen / 4;
+    P.usable = DEPTH == 16 && (CH == 2 ? (frameBytes & 15) == 0 : (frameBytes & 7) == 0);
+#pragma unroll
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+        const int idx = it * 64 + lane;
+        const int q = idx / GROUPS, grp = idx - q * GROUPS;
+        const int row = q * CH;
+        P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * CH * 2);
+        P.xs[it] = row * kXsStride + grp * 4;
+        const int32_t r = CH == 2 ? sh.rowMix[row] : 0;
+        P.wl[it] = r ? r : (1 << kMixBits);
+        P.wr[it] = r ? (1 << kMixBits) - r : 0;
+        P.vsel[it] = r ? -1 : 0;
+    }
+}
+
+template <int CH, int LPC>
+__device__ __forceinline__ void stage_load_fast(StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P, int j0)
+{
+    const int64_t byteOff = (int64_t)(j0 - kHist) * (CH * 2);
+#pragma unroll
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+        if constexpr (CH == 2) {
+            const int4 w4 = *(const int4 *)(P.pk[it] + byteOff);
+            R.v[it][0] = w4.x;
+            R.v[it][1] = w4.y;
+            R.v[it][2] = w4.z;
+            R.v[it][3] = w4.w;
+        } else {
+            const int2 w2 = *(const int2 *)(P.pk[it] + byteOff);
+            R.v[it][0] = w2.x;
+            R.v[it][1] = w2.y;
+        }
+    }
+}
+
+template <int CH, int LPC>
+__device__ __forceinline__ void stage_store_fast(const StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P,
+                                                 LmsShared<LPC> &sh)
+{
+#pragma unroll
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if constexpr (CH == 2) {
+                const int32_t l = (int16_t)R.v[it][t], r = R.v[it][t] >> 16;
+                // codec/matrix_enc.cu:72-99 with the mixRes = 0 case folded into the weights (4 l >> 2 == l)
+                sh.xs[P.xs[it] + t] = (__mul24(P.wl[it], l) + __mul24(P.wr[it], r)) >> kMixBits;
+                sh.xs[P.xs[it] + kXsStride + t] = P.vsel[it] ? l - r : r;
+            } else {
+                const int32_t w = R.v[it][t >> 1];
+                sh.xs[P.xs[it] + t] = (t & 1) ? (w >> 16) : (int32_t)(int16_t)w;
+            }
+        }
+    }
+}
+
 // The LDS operands of a step (the sample entering the lane's history window, top, in[j]) depend on nothing
 // the recurrence produces: the operands of block i+1 (8 steps) are fetched while block i computes.
 struct StepOps {
@@ -320,7 +393,7 @@ struct ChainJob {
 
 // A pass = one pc_block call over every chain of the wave: `num` samples adapt the row, residual positions
 // j < P go to dst[j * streamStride + stream] when store is set.
-template <int DEPTH, int CH, int LPC>
+template <int DEPTH, int CH, int LPC, bool WT = false>
 __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[4],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
                                          uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0)
@@ -341,14 +414,25 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     const uint32_t fStream = (uint32_t)__shfl((int)stream, fs * LPC);
     const int fNa = __shfl(J.na, fs * LPC);
     const uint32_t runTo = wave_max(J.active ? (store ? (P > num ? P : num) : num) : 0);
+    // flush: the lane's column inside a group of LPC rows, and the first row some lane does NOT own
+    const uint32_t half = (uint32_t)(lane / SLOTS);
+    const uint32_t voff = half * (uint32_t)streamStride + fStream;
+    const uint32_t fPmin = wave_min_u32(fP);
     StageRegs<CH, LPC> R;
+    StagePlan<CH, LPC> SP;
+    stage_plan<DEPTH, CH, LPC>(SP, sh, A.S.pcm, frameBytes, lane);
+    // staged window [j - kHist, j - kHist + kRowLen) inside every packet of the wave -> fast staging of tile j
+    const uint32_t nMinRows = wave_min_u32(J.active ? J.N : 0);
+    auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + kRowLen) <= nMinRows; };
     if (runTo > 0) {
         stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
         stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
     }
     for (int j0 = 0; j0 < (int)runTo; j0 += kTile) {
         const bool more = j0 + kTile < (int)runTo;
-        if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);  // in flight under the tile
+        const bool fastNext = more && interior(j0 + kTile);
+        if (fastNext) stage_load_fast<CH, LPC>(R, SP, j0 + kTile);  // in flight under the tile
+        else if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
         lds_order();
         const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
         run_tile<LPC>(a, V, L, j0, jEnd, chanBits);
@@ -362,24 +446,33 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 }
                 lds_order();
             }
-            // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams
+            // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams.  WT (fused launches):
+            // agent-scope stores, written through so that publish_rows has nothing to write back.
+            auto put = [&](int32_t *q, int32_t v) {
+                if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *q = v;
+            };
+            if ((uint32_t)(j0 + kTile) <= fPmin) {
+                // every lane owns every row of the tile: scalar row base + lane column, no predicate, no branch
+                int32_t *tileBase = dst + (uint64_t)j0 * streamStride;
+#pragma unroll
+                for (int it = 0; it < kTile / LPC; it++)
+                    put(tileBase + (uint64_t)(it * LPC) * streamStride + voff, sh.res[fs * kResStride + it * LPC + (int)half]);
+            } else {
 #pragma unroll 4
-            for (int it = 0; it < kTile / LPC; it++) {
-                const int jj = it * LPC + lane / SLOTS;
-                const uint32_t j = (uint32_t)(j0 + jj);
-                const int32_t v = sh.res[fs * kResStride + jj];
-                if (j < fP) {
-                    int32_t *q = dst + (uint64_t)j * streamStride + fStream;
-                    // fused final: write through (agent scope) so that the release below finds little to write back
-                    if (flag) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else *q = v;
+                for (int it = 0; it < kTile / LPC; it++) {
+                    const int jj = it * LPC + lane / SLOTS;
+                    const uint32_t j = (uint32_t)(j0 + jj);
+                    const int32_t v = sh.res[fs * kResStride + jj];
+                    if (j < fP) put(dst + (uint64_t)j * streamStride + fStream, v);
                 }
             }
             // fused final kernel: tell the coder waves how many residual rows are complete (every 4 tiles)
             if (flag && ((((j0 / kTile) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + kTile, (int)runTo), lane, (A.pubMask >> 31) != 0);
         }
         lds_order();
-        if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
+        if (fastNext) stage_store_fast<CH, LPC>(R, SP, sh);
+        else if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
     }
 }
 
@@ -557,8 +650,8 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         uint32_t *flag = A.flags + blockIdx.x;
         for (int r = 0; r <= kMaxRes; r++) {
             lms_setup<2>(sh, J, r, lane);
-            lms_pass<DEPTH, 2, 2>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
-                                  flag, (uint32_t)r << 16);
+            lms_pass<DEPTH, 2, 2, true>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain,
+                                        lane, flag, (uint32_t)r << 16);
         }
         store_row<2>(J, a, lane);
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);
@@ -623,17 +716,24 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
     const uint64_t strideB = 2ull * A.chainsPad, strideA = 5ull * A.chainsPad;
     GolF g;
     golf_reset(g);
-    // both planes are read for every row (uniform addresses, no branch); the lane's P2 picks the value
+    // Rows below P2 come from the last converge pass (resB), the tail from the mixRes = 4 search pass (resA).  P2 is
+    // the same for every full packet, so normally the row ADDRESS is picked with scalar selects and one load is
+    // issued per row; only waves that mix packet lengths read both planes and pick per lane.
     const int32_t *planeB = A.resB + (uint64_t)rs * A.chainsPad, *planeA = A.resA + (uint64_t)kMaxRes * A.chainsPad;
-    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) {
-        const int32_t b = (planeB + j * strideB)[chain];
-        if constexpr (CH == 2) {
-            const int32_t a = (planeA + j * strideA)[chain];
+    const uint32_t nMax = wave_max(n8);
+    const uint32_t p2lo = wave_min_u32(active ? P2 : 0xffffffffu), p2hi = wave_max(active ? P2 : 0u);
+    if (CH == 1 || p2lo >= p2hi) {
+        const uint32_t P2u = CH == 1 ? 0xffffffffu : p2hi;
+        golf_stream<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
+            const int32_t *row = j < P2u ? planeB + j * strideB : planeA + j * strideA;
+            return row[chain];
+        });
+    } else {
+        golf_stream<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
+            const int32_t b = (planeB + j * strideB)[chain], a = (planeA + j * strideA)[chain];
             return j < P2 ? b : a;
-        } else {
-            return b;
-        }
-    });
+        });
+    }
     if (active) A.cost2[t] = g.bits * 8 + 16 * na;  // :438, :447 / :899
 }
 
@@ -725,7 +825,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         load_row<2>(J, a, lane);
         lms_setup<2>(sh, J, best, lane);
         uint32_t *flag = A.flags + blockIdx.x;
-        lms_pass<DEPTH, CH, 2>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
+        lms_pass<DEPTH, CH, 2, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
         store_row<2>(J, a, lane);
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);  // nothing more will come (also covers inactive waves)
     } else {
