@@ -440,15 +440,19 @@ __device__ __forceinline__ uint32_t take(Fetch &&fetch32, uint64_t len, int64_t 
     return fetch32(0) >> (uint32_t)(-s);
 }
 
+// MSB-first bit writer over zero-initialised 32-bit words, one word-sized step per field (the header is built by
+// one lane while the rest of the workgroup waits: keep it short)
 struct HdrWriter {
     uint32_t *w;
     uint32_t pos;
-    __device__ void put(uint32_t v, uint32_t n)
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n)
     {
-        for (int i = (int)n - 1; i >= 0; i--) {
-            if ((v >> i) & 1u) w[pos >> 5] |= 0x80000000u >> (pos & 31);
-            pos++;
-        }
+        // n <= 32; v confined to n bits by the callers
+        const uint32_t i = pos >> 5, o = pos & 31;
+        const uint64_t x = ((uint64_t)v << (64 - n)) >> o;  // field left-aligned at bit o of a 64-bit window
+        w[i] |= (uint32_t)(x >> 32);
+        if (o + n > 32) w[i + 1] |= (uint32_t)x;
+        pos += n;
     }
 };
 
@@ -492,9 +496,13 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
         }
         hdrBits = h.pos;
     }
-    __syncthreads();
-
-    const uint64_t lenHdr = hdrBits;
+    // the header LENGTH follows from the record alone, so the bulk copies below need not wait for its bits
+    uint32_t hb = 3 + 4 + 12 + 4 + (partial ? 32u : 0u);
+    if (!rec.escape) {
+        hb += 16;
+        for (int c = 0; c < CH; c++) hb += 16 + 16 * rec.c[c].num;
+    }
+    const uint64_t lenHdr = hb;
     const uint64_t lenShift = rec.escape ? 0 : (uint64_t)N * CH * SHB * 8;
     const uint64_t lenU = rec.escape ? 0 : rec.c[0].bits;
     const uint64_t lenV = (rec.escape || CH == 1) ? 0 : rec.c[1].bits;
@@ -509,13 +517,79 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
     const uint32_t *wU = A.bitWords + (uint64_t)p * 2 * A.wcap;
     const uint32_t *wV = wU + A.wcap;
     const uint64_t outOff = A.offsets[p];
-    const uint32_t mis = (uint32_t)(outOff & 3);
+    const uint32_t mis = (uint32_t)(outOff & 15);  // work in words of a 16-byte aligned frame: 16-byte stores
     uint8_t *outAligned = A.out + (outOff - mis);
     const uint32_t nwords = (mis + nb + 3) / 4;
 
     auto sampleField = [&](uint32_t t) -> uint32_t { return (uint32_t)load_sample<DEPTH>(pk, t); };
 
+    // Bulk of a packet = the two channel bit strings (or the raw samples of an escape packet): output words that
+    // lie completely inside one of them are a plain funnel-shifted copy with a constant shift — no per-word
+    // segment search, independent loads.  Words touching a segment boundary (header, U|V seam, tail; a dozen per
+    // packet) and the 24-bit shift bytes take the general path below.
+    struct Span {
+        uint32_t w0, w1;  // aligned output words [w0, w1) fully inside the segment
+    };
+    auto span_of = [&](int64_t off, uint64_t len) {
+        const int64_t base = off + (int64_t)mis * 8;  // bit position from the aligned output start
+        Span sp;
+        sp.w0 = (uint32_t)((base + 31) >> 5);
+        sp.w1 = (uint32_t)((base + (int64_t)len) >> 5);
+        if (sp.w1 < sp.w0) sp.w1 = sp.w0;
+        return sp;
+    };
+    auto copy_span = [&](const Span &sp, int64_t off, auto &&srcWord) {
+        const uint32_t sh = (uint32_t)((int64_t)sp.w0 * 32 - (off + (int64_t)mis * 8));  // 0..31: source bit of word w0
+        auto one = [&](uint32_t w) {
+            const uint32_t i = w - sp.w0;
+            const uint32_t a = srcWord(i);
+            const uint32_t b = sh ? srcWord(i + 1) : 0u;  // exists: the output word ends inside the segment
+            const uint32_t v = sh ? __builtin_amdgcn_alignbit(a, b, 32 - sh) : a;
+            *(uint32_t *)(outAligned + (uint64_t)w * 4) = __builtin_bswap32(v);
+        };
+        // groups of four words = one 16-byte store, five independent loads in flight per lane (the copy is
+        // latency bound: bytes in flight per lane are what sets its rate)
+        const uint32_t g0 = (sp.w0 + 3) & ~3u, g1 = sp.w1 & ~3u;
+        if (g0 < g1) {
+            for (uint32_t w = sp.w0 + threadIdx.x; w < g0; w += blockDim.x) one(w);
+            for (uint32_t w = g0 + 4 * threadIdx.x; w < g1; w += 4 * blockDim.x) {
+                const uint32_t i = w - sp.w0;
+                uint32_t a[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) a[q] = (q < 4 || sh) ? srcWord(i + q) : 0u;
+                uint4 v;
+                v.x = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[0], a[1], 32 - sh) : a[0]);
+                v.y = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[1], a[2], 32 - sh) : a[1]);
+                v.z = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[2], a[3], 32 - sh) : a[2]);
+                v.w = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[3], a[4], 32 - sh) : a[3]);
+                *(uint4 *)(outAligned + (uint64_t)w * 4) = v;
+            }
+            for (uint32_t w = g1 + threadIdx.x; w < sp.w1; w += blockDim.x) one(w);
+        } else {
+            for (uint32_t w = sp.w0 + threadIdx.x; w < sp.w1; w += blockDim.x) one(w);
+        }
+    };
+    Span spU = {0, 0}, spV = {0, 0}, spR = {0, 0};
+    if (!rec.escape) {
+        spU = span_of(offU, lenU);
+        copy_span(spU, offU, [&](uint32_t i) { return wU[i]; });
+        if constexpr (CH == 2) {
+            spV = span_of(offV, lenV);
+            copy_span(spV, offV, [&](uint32_t i) { return wV[i]; });
+        }
+    } else if constexpr (DEPTH == 16) {
+        // raw 16-bit samples, MSB first: two little-endian samples per PCM word, swapped into place by a rotate
+        spR = span_of(offRaw, lenRaw);
+        const uint32_t *pw = (const uint32_t *)pk;  // 16-byte aligned packet (checked by the C entry point)
+        copy_span(spR, offRaw, [&](uint32_t i) {
+            const uint32_t x = pw[i];
+            return (x << 16) | (x >> 16);
+        });
+    }
+
+    __syncthreads();  // header words complete
     for (uint32_t aw = threadIdx.x; aw < nwords; aw += blockDim.x) {
+        if ((aw >= spU.w0 && aw < spU.w1) || (aw >= spV.w0 && aw < spV.w1) || (aw >= spR.w0 && aw < spR.w1)) continue;
         const int64_t bp = (int64_t)aw * 32 - (int64_t)mis * 8;
         uint32_t v = take([&](uint64_t s0) { return words_fetch32(hdr, (uint32_t)lenHdr, (uint32_t)s0); }, lenHdr, bp);
         if (!rec.escape) {
