@@ -125,7 +125,7 @@ bool use_lane_encoder()
 }
 
 struct DecLayout {
-    uint64_t recs, resid, total;
+    uint64_t recs, resid, words, capWords, total;
 };
 
 DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
@@ -135,9 +135,22 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
     L.recs = off;
     off = align_up(off + (uint64_t)numPackets * sizeof(DecRec), 256);
     L.resid = off;
-    off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4, 256);
+    off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
+    // the stream re-staged as MSB-first words, zero padded (alac_decode_v1.hip): every packet at its largest
+    L.words = off;
+    L.capWords = ((uint64_t)numPackets * alac_hip_encode_max_output_bytes(f, 1) + 3) / 4 + 64;
+    off = align_up(off + L.capWords * 4, 256);
     L.total = off;
     return L;
+}
+
+bool use_lane_decoder()
+{
+    static const bool v = [] {
+        const char *e = getenv("ALAC_HIP_DECODER");
+        return e && strcmp(e, "lane") == 0;
+    }();
+    return v;
 }
 
 struct DevBuf {
@@ -485,7 +498,9 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.pcmOut = d_pcm_out;
     da.numSamplesOut = d_num_samples_out;
     da.statusOut = d_status;
-    hipError_t e = launch_decode(da, ctx->stream);
+    hipError_t e = use_lane_decoder()
+                       ? launch_decode(da, ctx->stream)
+                       : launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "decode launch", e);
     return ALAC_HIP_noErr;
 }

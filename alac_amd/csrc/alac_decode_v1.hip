@@ -1,0 +1,665 @@
+// alac_decode_v1.hip — batch ALAC decode, second generation (the default; ALAC_HIP_DECODER=lane selects the
+// first one in alac_decode.hip).
+//
+//   k_dec_stage      copy of the packed stream into 32-bit words, MSB first (byte swapped), zero padded: the
+//                    bit readers below then work on aligned words and may over-read safely
+//   k_dec_entropy    one lane per packet: element/header parse (codec/ALACDecoder.cu:571-1002), then dyn_decomp
+//                    (codec/ag_dec.c:272-362) of U and V — or the raw samples of an escape element — from a
+//                    64-bit register bit window refilled out of a per-lane LDS ring; the ring is re-staged from
+//                    the word stream every 16 symbols with 16-byte loads issued a round ahead.  The channel that
+//                    is decoded is serial by nature (V starts where U's bits end): the parallelism is 10 000
+//                    packets wide, and a symbol costs ~70 instructions instead of ~5 dependent byte loads.
+//   k_dec_unpc       unpc_block (codec/dp_dec.c:55-381), in place
+//   k_dec_unmix      un-mix + shift-byte re-attach + PCM packing (codec/ALACDecoder.cu:193-563)
+//
+// Sample planes are CHAIN-major here: int32 [packet][channel][frameSize], so every lane streams through its own
+// contiguous row (the entropy lanes drift apart on zero runs, which rules out the sample-major layout of the
+// encoder), and the un-mix reads both channels of a packet coalesced along the sample index.
+#include <cstdlib>
+#include "alac_dev.hpp"
+#include "alac_kernels.hpp"
+#include "alac_unpc.hpp"
+#include "alac_lms.hpp"
+
+namespace alacdev {
+
+constexpr int kDecRound = 16;    // symbols decoded between two restagings of the LDS ring
+constexpr int kWinWords = 16;    // words staged per lane per round (64 bytes)
+constexpr int kWinStride = 33;   // LDS words per lane: a circular ring of 32 (+1: odd stride, conflict-free columns)
+
+// ---- k_dec_stage ---------------------------------------------------------------------------------
+// words[i] = bytes 4i .. 4i+3 of the stream as one MSB-first word; zeros from the end of the stream to `capWords`
+__global__ __launch_bounds__(256) void k_dec_stage(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets,
+                                                   uint32_t *words, uint64_t capWords)
+{
+    const uint64_t total = offsets[numPackets];
+    const uint64_t fullWords = total >> 2;
+    const bool aligned = ((uintptr_t)stream & 3) == 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capWords; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        if (i < fullWords && aligned) {
+            v = __builtin_bswap32(((const uint32_t *)stream)[i]);
+        } else if (i * 4 < total) {
+            for (uint32_t b = 0; b < 4; b++) {
+                const uint64_t bi = i * 4 + b;
+                v = (v << 8) | (bi < total ? stream[bi] : 0u);
+            }
+        }
+        words[i] = v;
+    }
+}
+
+// ---- per-lane bit window ---------------------------------------------------------------------------
+struct BitWin {
+    uint64_t win;        // next bits, left aligned
+    uint32_t have;       // valid bits in win (>= 32 between operations)
+    uint32_t idx;        // ring index of the look-ahead word
+    uint32_t nw;         // look-ahead word (already read from the ring)
+    uint32_t pos;        // bits consumed since the packet's first staged word
+    uint32_t org;        // word index that lives in ring slot 0
+    const uint32_t *ring;
+};
+
+__device__ __forceinline__ uint32_t bw_peek(const BitWin &b) { return (uint32_t)(b.win >> 32); }
+
+__device__ __forceinline__ void bw_skip(BitWin &b, uint32_t n)  // n <= 32
+{
+    b.win <<= n;
+    b.have -= n;
+    b.pos += n;
+    if (b.have < 32) {
+        b.win |= (uint64_t)b.nw << (32 - b.have);
+        b.have += 32;
+        b.idx++;
+        b.nw = b.ring[(b.idx - b.org) & 31u];
+    }
+}
+
+__device__ __forceinline__ uint32_t bw_get(BitWin &b, uint32_t n)  // 1 <= n <= 32
+{
+    const uint32_t v = bw_peek(b) >> (32 - n);
+    bw_skip(b, n);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+struct DecV1Args {
+    DecodeArgs d;
+    const uint32_t *words;   // staged stream
+    uint64_t capWords;
+    int32_t *plane;          // [packet][channel][frameSize]
+};
+
+// lane states of the entropy kernel
+enum : uint32_t { kStIdle = 0, kStGolomb = 1, kStRaw = 2 };
+
+// ---- k_dec_header: element / header parse, once per packet, with the plain byte reader
+// (codec/ALACDecoder.cu:600-700).  Leaves the record, the payload position and the status behind.
+__global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const int lane = threadIdx.x;
+    const uint32_t p = blockIdx.x * 64u + lane;
+    const bool live = p < A.numPackets;
+    const uint64_t off = live ? A.offsets[p] : 0;
+    const uint64_t nbytes = live ? A.offsets[p + 1] - off : 0;
+    const uint8_t *base = A.stream + off;
+    DecRec *rec = A.recs + (live ? p : 0);
+
+    uint64_t hpos = 0;
+    uint32_t numSamples = A.frameSize, ech = 0, shb = 0, chanBits = 0, esc = 0;
+    int32_t status = 0;
+    uint32_t pbU = A.pb, pbV = A.pb;
+    DecRec R;
+    R.numSamples = 0;
+    R.escape = 0;
+    R.mixBits = R.mixRes = 0;
+    R.bytesShifted = 0;
+    R.elementChannels = 0;
+    R.shiftPos = 0;
+    bool haveElement = false;
+    if (live) {
+        bool done = false;
+        while (!done && status == 0) {
+            if (!((hpos >> 3) < nbytes)) {  // :615
+                status = -50;
+                break;
+            }
+            const uint32_t tag = read_bits(base, nbytes, hpos, 3);
+            switch (tag) {
+            case 0:    // ID_SCE
+            case 3:    // ID_LFE
+            case 1: {  // ID_CPE
+                ech = (tag == 1) ? 2u : 1u;
+                if (ech != A.numChannels) {  // > 2-channel layouts (several elements) are not built yet
+                    status = -4;
+                    break;
+                }
+                (void)read_bits(base, nbytes, hpos, 4);
+                if (read_bits(base, nbytes, hpos, 12) != 0) {  // :633 / :768
+                    status = -50;
+                    break;
+                }
+                const uint32_t hb = read_bits(base, nbytes, hpos, 4);
+                const uint32_t partial = hb >> 3;
+                shb = (hb >> 1) & 3;
+                esc = hb & 1;
+                if (shb == 3) {
+                    status = -50;
+                    break;
+                }
+                chanBits = A.bitDepth - shb * 8 + (ech == 2 ? 1 : 0);
+                if (partial) numSamples = read_bits(base, nbytes, hpos, 32);
+                if (numSamples > A.frameSize) {
+                    status = -50;
+                    break;
+                }
+                R.elementChannels = ech;
+                if (!esc) {
+                    R.mixBits = (int32_t)read_bits(base, nbytes, hpos, 8);
+                    R.mixRes = (int8_t)read_bits(base, nbytes, hpos, 8);
+                    for (uint32_t c = 0; c < ech; c++) {
+                        uint32_t b = read_bits(base, nbytes, hpos, 8);
+                        rec->c[c].mode = (uint16_t)(b >> 4);
+                        rec->c[c].denShift = (uint16_t)(b & 0xf);
+                        b = read_bits(base, nbytes, hpos, 8);
+                        rec->c[c].pbFactor = (uint16_t)(b >> 5);
+                        rec->c[c].num = (uint16_t)(b & 0x1f);
+                        if (c == 0) pbU = (A.pb * (b >> 5)) / 4;  // :825
+                        else pbV = (A.pb * (b >> 5)) / 4;        // :841
+                        for (uint32_t i = 0; i < (b & 0x1f); i++)
+                            rec->c[c].coefs[i] = (int16_t)read_bits(base, nbytes, hpos, 16);
+                    }
+                    R.shiftPos = hpos;
+                    if (shb) hpos += (uint64_t)shb * 8 * ech * numSamples;
+                    R.bytesShifted = shb;
+                } else {
+                    chanBits = A.bitDepth;  // :697-727 / :856-896 uncompressed element
+                    R.escape = 1;
+                }
+                R.numSamples = numSamples;
+                haveElement = true;
+                done = true;  // channelIndex >= numChannels, :967
+                break;
+            }
+            case 2:  // ID_CCE
+            case 5:  // ID_PCE
+                status = -50;
+                break;
+            case 4: {  // ID_DSE :1033-1059
+                (void)read_bits(base, nbytes, hpos, 4);
+                const uint32_t align = read_bits(base, nbytes, hpos, 1);
+                uint32_t count = read_bits(base, nbytes, hpos, 8);
+                if (count == 255) count += read_bits(base, nbytes, hpos, 8);
+                if (align && (hpos & 7)) hpos += 8 - (hpos & 7);
+                hpos += (uint64_t)count * 8;
+                if ((hpos + 7) / 8 > nbytes) status = -50;
+                break;
+            }
+            case 6: {  // ID_FIL :1012-1027
+                int32_t count = (int32_t)read_bits(base, nbytes, hpos, 4);
+                if (count == 15) count += (int32_t)read_bits(base, nbytes, hpos, 8) - 1;
+                hpos += (uint64_t)count * 8;
+                if ((hpos + 7) / 8 > nbytes) status = -50;
+                break;
+            }
+            default:  // ID_END before any audio element
+                done = true;
+                break;
+            }
+        }
+    }
+
+    if (live) {
+        rec->numSamples = R.numSamples;
+        rec->escape = R.escape;
+        rec->mixBits = R.mixBits;
+        rec->mixRes = R.mixRes;
+        rec->bytesShifted = R.bytesShifted;
+        rec->elementChannels = haveElement ? R.elementChannels : 0;
+        rec->shiftPos = R.shiftPos;
+        rec->status = status;
+        rec->pad = (uint32_t)hpos;  // first payload bit (entropy coded or raw), from the packet start
+        A.statusOut[p] = status;
+        A.numSamplesOut[p] = status == 0 ? R.numSamples : 0;
+    }
+    (void)pbU;
+    (void)pbV;
+    (void)chanBits;
+    (void)lane;
+}
+
+// ---- k_dec_raw: uncompressed (escape) elements are fixed-width fields, i.e. not serial at all: one thread per
+// sample-frame reads its fields straight from the staged words (codec/ALACDecoder.cu:697-727 / :856-896)
+__global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const uint32_t p = blockIdx.y;
+    const DecRec *rec = A.recs + p;
+    if (rec->status != 0 || !rec->escape || rec->elementChannels == 0) return;
+    const uint32_t ech = rec->elementChannels, n = rec->numSamples, w = A.bitDepth;
+    const uint64_t off = A.offsets[p];
+    const uint64_t bitBase = (off & 3) * 8 + rec->pad;
+    const uint32_t *words = V.words + (off >> 2);
+    int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        for (uint32_t c = 0; c < ech; c++) {
+            const uint64_t b = bitBase + ((uint64_t)j * ech + c) * w;
+            const uint32_t i = (uint32_t)(b >> 5), sh = (uint32_t)(b & 31);
+            const uint64_t two = ((uint64_t)words[i] << 32) | words[i + 1];
+            const uint32_t v = (uint32_t)((two << sh) >> 32) >> (32 - w);
+            (rowU + c * A.frameSize)[j] = (int32_t)(v << (32 - w)) >> (32 - w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
+{
+    __shared__ uint32_t ring[64 * kWinStride];
+    const DecodeArgs &A = V.d;
+    const int lane = threadIdx.x;
+    const uint32_t p = blockIdx.x * 64u + lane;
+    const bool live = p < A.numPackets;
+    const uint64_t off = live ? A.offsets[p] : 0;
+    const uint64_t nbytes = live ? A.offsets[p + 1] - off : 0;
+    DecRec *rec = A.recs + (live ? p : 0);
+    int32_t status = live ? rec->status : 0;
+    const uint32_t ech = live ? rec->elementChannels : 0;
+    const uint32_t numSamples = live ? rec->numSamples : 0;
+    const uint32_t chanBits = A.bitDepth - (live ? rec->bytesShifted : 0) * 8 + (ech == 2 ? 1 : 0);
+    const uint32_t pbU = live ? (A.pb * rec->c[0].pbFactor) / 4 : A.pb;  // :825
+    const uint32_t pbV = live ? (A.pb * rec->c[1].pbFactor) / 4 : A.pb;  // :841
+    const uint64_t hpos = live ? rec->pad : 0;
+    const bool coded = live && status == 0 && ech != 0 && !rec->escape && numSamples > 0;
+
+    // ---- payload: window reader over the staged words ----
+    // bit positions below are relative to the packet's first staged word (the packet starts at bit 8 * (off & 3))
+    const uint64_t wordBase = off >> 2;
+    const uint32_t bit0 = (uint32_t)(off & 3) * 8;
+    const uint32_t limit = bit0 + (uint32_t)nbytes * 8;  // maxPos of ag_dec.c:295
+    const uint32_t wb = (1u << A.kb) - 1;
+    int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
+
+    uint32_t state = coded ? kStGolomb : kStIdle;
+    uint32_t chan = 0;             // Golomb: channel being decoded
+    uint32_t c = 0;                // Golomb: sample index in the channel; raw: field index
+    uint32_t mb = A.mb, zmode = 0, pb = pbU;
+
+    // ---- circular ring of 32 staged words per lane; word t (relative to the lane's first payload word) lives in
+    // slot (t - cur0) & 31.  16 words are fetched whenever 16 slots are free, one round (16 symbols) before they
+    // are written into the ring, so the global latency is covered by the round's own work.
+    BitWin bw;
+    bw.ring = ring + lane * kWinStride;
+    const uint32_t pos0 = bit0 + (uint32_t)hpos;
+    const uint32_t cur0 = pos0 >> 5;
+    uint32_t F = cur0;  // first word not yet in the ring
+    auto fetch16 = [&](uint32_t rel, uint32_t (&q)[16]) {
+        uint64_t w = wordBase + rel;
+        const uint64_t lastStart = V.capWords - kWinWords;  // corrupt input may run past the packet: stay inside
+        w = w < lastStart ? w : lastStart;
+        const uint32_t *sw = V.words + w;
+#pragma unroll
+        for (int i = 0; i < 16; i++) q[i] = sw[i];
+    };
+    auto write16 = [&](uint32_t rel, const uint32_t (&q)[16]) {
+        uint32_t *dst = ring + lane * kWinStride + ((rel - cur0) & 31u);
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[i] = q[i];
+    };
+    uint32_t q[16];
+    fetch16(F, q);
+    write16(F, q);
+    F += 16;
+    bool pending = false;
+    uint32_t pendBase = 0;
+    {
+        // prime the window at pos0
+        const uint32_t sh = pos0 & 31;
+        bw.win = (((uint64_t)bw.ring[0] << 32) | bw.ring[1]) << sh;
+        bw.have = 64 - sh;
+        bw.idx = cur0 + 2;
+        bw.nw = bw.ring[2];
+        bw.pos = pos0;
+        bw.org = cur0;
+    }
+
+    while (__any(state != kStIdle)) {
+        if (pending) {
+            write16(pendBase, q);
+            F = pendBase + 16;
+            pending = false;
+        }
+        if (state != kStIdle && F - (bw.pos >> 5) <= 16) {
+            fetch16(F, q);
+            pending = true;
+            pendBase = F;
+        }
+        asm volatile("" ::: "memory");
+
+        for (int it = 0; it < kDecRound; it++) {
+            const bool room = F * 32 - bw.pos >= 160;
+            if (state == kStGolomb && room) {
+                if (!(bw.pos < limit)) {  // ag_dec.c:302
+                    status = -50;
+                    state = kStIdle;
+                } else {
+                    // one residual: dyn_get_32bit (ag_dec.c:220-270)
+                    uint32_t k = (uint32_t)lg3a(mb >> kQBShift);
+                    k = k > A.kb ? A.kb : k;
+                    const uint32_t m = (1u << k) - 1;
+                    uint32_t stream = bw_peek(bw);
+                    const uint32_t pre = (uint32_t)__builtin_clz(~stream | 1u);  // leading ones, at most 31
+                    uint32_t n;
+                    if (pre >= kMaxPrefix) {
+                        bw_skip(bw, kMaxPrefix);
+                        n = bw_get(bw, chanBits);
+                    } else {
+                        n = pre;
+                        uint32_t used = pre + 1;
+                        if (k != 1) {
+                            const uint32_t v = (stream << (pre + 1)) >> (32 - k);
+                            n = pre * m;
+                            used += k - 1;
+                            if (v >= 2) {
+                                n += v - 1;
+                                used += 1;
+                            }
+                        }
+                        bw_skip(bw, used);
+                    }
+                    const uint32_t nd = n + zmode;
+                    const int32_t mult = (-(int32_t)(nd & 1)) | 1;
+                    (rowU + chan * A.frameSize)[c] = (int32_t)((nd + 1) >> 1) * mult;
+                    c++;
+                    mb = pb * nd + mb - ((pb * mb) >> kQBShift);
+                    if (n > kMeanClamp) mb = kMeanClamp;
+                    zmode = 0;
+                    if (((mb << 2) < (1u << kQBShift)) && (c < numSamples)) {
+                        // zero run (ag_dec.c:324-352): the plane is pre-zeroed, only the index moves
+                        zmode = 1;
+                        const uint32_t kz = (uint32_t)(lead(mb) - 24 + (int32_t)((mb + 16u) >> 6));
+                        const uint32_t mz = ((1u << kz) - 1) & wb;
+                        stream = bw_peek(bw);
+                        const uint32_t prz = (uint32_t)__builtin_clz(~stream | 1u);
+                        uint32_t nz;
+                        if (prz >= kMaxPrefix) {
+                            nz = (stream << kMaxPrefix) >> (32 - kMaxRunBits);
+                            bw_skip(bw, kMaxPrefix + kMaxRunBits);
+                        } else {
+                            const uint32_t v = (stream << (prz + 1)) >> (32 - kz);
+                            nz = prz * mz + v - 1;
+                            uint32_t used = prz + 1 + kz;
+                            if (v < 2) {
+                                nz -= (v - 1);
+                                used -= 1;
+                            }
+                            bw_skip(bw, used);
+                        }
+                        if (!((uint64_t)c + nz <= (uint64_t)numSamples)) {  // :341
+                            status = -50;
+                            state = kStIdle;
+                        }
+                        c += nz;
+                        if (nz >= 65535) zmode = 0;
+                        mb = 0;
+                    }
+                    if (state != kStIdle && c >= numSamples) {
+                        // channel complete: ag_dec.c:359 end check, then the next channel starts where this one ended
+                        if ((uint64_t)(bw.pos - bit0 + 7) / 8 > nbytes) {
+                            status = -50;
+                            state = kStIdle;
+                        } else if (chan + 1 < ech) {
+                            chan++;
+                            c = 0;
+                            mb = A.mb;
+                            zmode = 0;
+                            pb = pbV;
+                        } else {
+                            state = kStIdle;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    if (live && status != rec->status) {
+        rec->status = status;
+        A.statusOut[p] = status;
+        A.numSamplesOut[p] = 0;
+    }
+}
+
+// ---- unpc_block (codec/dp_dec.c:55-381), in place over the chain's row ----
+// Fast kernel: what every ALAC encoder in the wild emits for 16/24-bit material and all this library's encoder
+// emits — mode 0, denShift 9, 4 or 8 taps — on the 2-lanes-per-chain mapping of alac_lms.hpp (32 chains per
+// wave).  Everything else (first-order mode, other tap counts or shifts, tiny packets) goes to the lane-serial
+// generic kernel.  The two kernels partition the chains with unpc_fast_ok.
+__device__ __forceinline__ bool unpc_fast_ok(const DecodeArgs &A, const DecRec *rec, uint32_t ch)
+{
+    if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return false;
+    const DecChan &c = rec->c[ch];
+    return (A.frameSize & 7) == 0 && rec->numSamples >= 16 && c.mode == 0 && c.denShift == kDenShift &&
+           (c.num == 4 || c.num == 8);
+}
+
+// the first 16 samples (warm-up positions + a few regular steps), lane-serial; leaves coefficients and outputs
+template <int NA>
+__device__ __forceinline__ void unpc_head16(const int32_t (&del)[16], int32_t (&out)[16], int32_t (&a8)[8],
+                                            uint32_t chanshift)
+{
+    Lms<NA> s;
+#pragma unroll
+    for (int k = 0; k < NA; k++) s.a[k] = a8[k];
+#pragma unroll
+    for (int k = 0; k <= NA; k++) s.h[k] = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        int32_t o;
+        if (j == 0) {
+            o = del[0];
+            lms_push<NA>(s, o);
+        } else if (j <= NA) {
+            o = sext(del[j] + s.h[0], chanshift);
+            lms_push<NA>(s, o);
+        } else {
+            o = lms_step_dec<NA>(s, del[j], chanshift, kDenShift);
+        }
+        out[j] = o;
+    }
+#pragma unroll
+    for (int k = 0; k < NA; k++) a8[k] = s.a[k];
+}
+
+__global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const int lane = threadIdx.x;
+    const uint64_t chain = (uint64_t)blockIdx.x * 32u + lane / 2;
+    const bool inRange = chain < (uint64_t)A.numPackets * A.numChannels;
+    const uint32_t p = inRange ? (uint32_t)(chain / A.numChannels) : 0, ch = inRange ? (uint32_t)(chain % A.numChannels) : 0;
+    const DecRec *rec = A.recs + p;
+    const bool active = inRange && unpc_fast_ok(A, rec, ch);
+    if (!__any(active)) return;
+    const uint32_t n = active ? rec->numSamples : 0;
+    const int na = active ? (int)rec->c[ch].num : 4;
+    const uint32_t chanbits = A.bitDepth - (active ? rec->bytesShifted : 0) * 8 + ((active ? rec->elementChannels : 1) == 2 ? 1 : 0);
+    int32_t *row = V.plane + (inRange ? chain : 0) * A.frameSize;
+    const bool writer = active && (lane & 1) == 0;
+
+    // ---- head: both lanes of the pair compute the same 16 samples, no exchange needed to set up the windows ----
+    int32_t d16[16], o16[16], a8[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int4 t = active ? ((const int4 *)row)[q] : make_int4(0, 0, 0, 0);
+        d16[4 * q] = t.x;
+        d16[4 * q + 1] = t.y;
+        d16[4 * q + 2] = t.z;
+        d16[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) a8[k] = (active && k < na) ? (int32_t)rec->c[ch].coefs[k] : 0;
+    if (na == 8) unpc_head16<8>(d16, o16, a8, 32 - chanbits);
+    else unpc_head16<4>(d16, o16, a8, 32 - chanbits);
+    if (writer) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) ((int4 *)row)[q] = make_int4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]);
+    }
+    const LmsDecLane L = make_dec_lane(lane, na);
+    int32_t a[4], w[4], tp;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a[i] = L.h ? a8[4 + i] : a8[i];
+        w[i] = (L.h ? o16[11 - i] : o16[15 - i]) & L.feed;
+    }
+    tp = (na == 8 ? o16[7] : o16[11]) & L.feed;
+
+    // ---- 8-step blocks; the residuals of block i+1 are loaded while block i computes ----
+    const uint32_t nMax = wave_max_u32(n);
+    auto load8 = [&](uint32_t jb, int32_t (&d)[8]) {
+        // rows are frameSize long and the plane is padded, so the (unused) over-read of the last block stays inside
+        const int4 t0 = *(const int4 *)(row + jb), t1 = *(const int4 *)(row + jb + 4);
+        d[0] = t0.x; d[1] = t0.y; d[2] = t0.z; d[3] = t0.w;
+        d[4] = t1.x; d[5] = t1.y; d[6] = t1.z; d[7] = t1.w;
+    };
+    int32_t dA[8], dB[8];
+    load8(16, dA);
+    auto block = [&](uint32_t jb, const int32_t (&cur)[8], int32_t (&nxt)[8]) {
+        load8(jb + 8, nxt);
+        int32_t o[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++) o[s2] = lms4_step_dec(a, w, tp, cur[s2], L, chanbits);
+        if (writer && jb < n) {
+            *(int4 *)(row + jb) = make_int4(o[0], o[1], o[2], o[3]);
+            *(int4 *)(row + jb + 4) = make_int4(o[4], o[5], o[6], o[7]);
+        }
+    };
+    for (uint32_t jb = 16; jb < nMax; jb += 16) {
+        block(jb, dA, dB);
+        if (jb + 8 < nMax) block(jb + 8, dB, dA);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dec_unpc(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const uint64_t gid = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (gid >= (uint64_t)A.numPackets * A.numChannels) return;
+    const uint32_t p = (uint32_t)(gid / A.numChannels), ch = (uint32_t)(gid % A.numChannels);
+    const DecRec *rec = A.recs + p;
+    if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return;
+    if (unpc_fast_ok(A, rec, ch)) return;  // k_dec_unpc_fast's
+    const uint32_t chanbits = A.bitDepth - rec->bytesShifted * 8 + (rec->elementChannels == 2 ? 1 : 0);
+    int32_t *row = V.plane + ((uint64_t)p * A.numChannels + ch) * A.frameSize;
+    const DecChan &c = rec->c[ch];
+    // :829-838: mode != 0 runs the first-order pass first
+    if (c.mode != 0) unpc_first_order(row, 1, rec->numSamples, 32 - chanbits);
+    unpc_any(row, 1, rec->numSamples, c.coefs, c.num, chanbits, c.denShift);
+}
+
+// ---- un-mix + pack (gpu_unmixNN / gpu_copyPredictorToNN, codec/ALACDecoder.cu:193-495) ----
+template <int DEPTH>
+__device__ __forceinline__ void put_sample(uint8_t *q, int32_t x)
+{
+    if constexpr (DEPTH == 16) {
+        *(int16_t *)q = (int16_t)x;
+    } else if constexpr (DEPTH == 32) {
+        *(int32_t *)q = x;
+    } else {
+        if constexpr (DEPTH == 20) x = (int32_t)((uint32_t)x << 4);
+        q[0] = (uint8_t)x;
+        q[1] = (uint8_t)(x >> 8);
+        q[2] = (uint8_t)(x >> 16);
+    }
+}
+
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const uint32_t p = blockIdx.y;
+    const DecRec *rec = A.recs + p;
+    if (rec->status != 0) return;
+    const uint32_t n = rec->numSamples, shb = rec->bytesShifted;
+    const int32_t mixRes = rec->mixRes, mixBits = rec->mixBits;
+    const int32_t *u = V.plane + (uint64_t)p * CH * A.frameSize;
+    const int32_t *v = u + A.frameSize;
+    constexpr uint32_t BPS = bytes_per_sample(DEPTH);
+    uint8_t *out = A.pcmOut + (uint64_t)p * A.frameSize * CH * BPS;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        int32_t l, r = 0;
+        if constexpr (CH == 2) {
+            const int32_t uu = u[j], vv = v[j];
+            if (mixRes != 0) {
+                l = uu + vv - ((mixRes * vv) >> mixBits);
+                r = l - vv;
+            } else {
+                l = uu;
+                r = vv;
+            }
+        } else {
+            l = u[j];
+        }
+        if (shb != 0 && DEPTH >= 24) {
+            const uint8_t *base = A.stream + A.offsets[p];
+            const uint64_t nbytes = A.offsets[p + 1] - A.offsets[p];
+            uint64_t sp = rec->shiftPos + (uint64_t)j * CH * shb * 8;
+            l = (int32_t)(((uint32_t)l << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
+            if constexpr (CH == 2) r = (int32_t)(((uint32_t)r << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
+        }
+        uint8_t *q = out + (uint64_t)j * CH * BPS;
+        if constexpr (DEPTH == 16 && CH == 2) {
+            *(uint32_t *)q = ((uint32_t)(uint16_t)l) | ((uint32_t)r << 16);
+        } else {
+            put_sample<DEPTH>(q, l);
+            if constexpr (CH == 2) put_sample<DEPTH>(q + BPS, r);
+        }
+    }
+}
+
+template <int DEPTH>
+static void launch_unmix_v1(const DecV1Args &V, hipStream_t st)
+{
+    const uint32_t bx = (V.d.frameSize + 1023) / 1024;
+    dim3 grid(bx ? bx : 1, V.d.numPackets);
+    if (V.d.numChannels == 2)
+        hipLaunchKernelGGL((k_dec_unmix<DEPTH, 2>), grid, dim3(256), 0, st, V);
+    else
+        hipLaunchKernelGGL((k_dec_unmix<DEPTH, 1>), grid, dim3(256), 0, st, V);
+}
+
+hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, hipStream_t st)
+{
+    if (da.numPackets == 0) return hipSuccess;
+    DecV1Args V;
+    V.d = da;
+    V.words = words;
+    V.capWords = capWords;
+    V.plane = plane;
+    const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
+    (void)hipMemsetAsync(plane, 0, planeBytes, st);  // zero runs only move the index (k_dec_entropy)
+    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
+    hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
+    hipLaunchKernelGGL(k_dec_raw, dim3((da.frameSize + 1023) / 1024, da.numPackets), dim3(256), 0, st, V);
+    hipLaunchKernelGGL(k_dec_entropy, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
+    const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
+    hipLaunchKernelGGL(k_dec_unpc_fast, dim3((uint32_t)((lanes + 31) / 32)), dim3(64), 0, st, V);
+    hipLaunchKernelGGL(k_dec_unpc, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
+    switch (da.bitDepth) {
+    case 16: launch_unmix_v1<16>(V, st); break;
+    case 20: launch_unmix_v1<20>(V, st); break;
+    case 24: launch_unmix_v1<24>(V, st); break;
+    case 32: launch_unmix_v1<32>(V, st); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace alacdev

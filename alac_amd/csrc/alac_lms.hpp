@@ -130,4 +130,87 @@ __device__ __forceinline__ int32_t lms4_step(int32_t (&a)[4], const int32_t (&w)
     return del;
 }
 
+// ---- decode direction (unpc_block, codec/dp_dec.c:55-381) with the same lane mapping ----
+// The residual `del` is an INPUT here, so the coefficient update (same thresholds, same signs as pc_block) is off
+// the dependent chain altogether; what is serial is out[j-1] -> b_0 -> tap sum -> out[j].  The history windows
+// hold the chain's own outputs: lane h = 0 keeps out[j-1..j-4], lane h = 1 out[j-5..j-8]; the sample leaving
+// lane 0's window enters lane 1's, and the one leaving the window of the last active tap is the next "top"
+// (one DPP exchange per step for both).
+struct LmsDecLane {
+    int32_t h;
+    int32_t wg[4];
+    int32_t c255, carryMask;
+    int32_t topMine;   // -1 on the lane whose dropped sample becomes the next top (h = 1 for 8 taps, h = 0 for 4)
+    int32_t takeOut;   // -1 on h = 0: the new output enters this lane's window
+    int32_t feed;      // 0 on a lane that holds no active tap (h = 1 of a 4-tap chain): it is fed zeros, so its
+                       // b, its signs and therefore its coefficients stay 0
+};
+
+__device__ __forceinline__ LmsDecLane make_dec_lane(int lane, int na)
+{
+    LmsDecLane L;
+    L.h = lane & 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int kk = 4 * L.h + i;
+        L.wg[i] = kk < na ? na - kk : 0;
+    }
+    L.c255 = L.h == 0 ? 255 : 0;
+    L.carryMask = L.h == 0 ? -1 : 0;
+    L.topMine = (L.h == (na == 8 ? 1 : 0)) ? -1 : 0;
+    L.takeOut = L.h == 0 ? -1 : 0;
+    L.feed = (L.h == 0 || na == 8) ? -1 : 0;
+    return L;
+}
+
+// one unpc step: returns out[j]; updates a[], the window w[] and tp (the "top" of the NEXT step)
+__device__ __forceinline__ int32_t lms4_step_dec(int32_t (&a)[4], int32_t (&w)[4], int32_t &tp, int32_t del,
+                                                 const LmsDecLane &L, uint32_t chanbits)
+{
+    int32_t b[4], sb[4];
+    uint32_t tpos[4], tneg[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        b[i] = tp - w[i];
+        const int32_t ab = max(b[i], -b[i]);
+        tpos[i] = (uint32_t)ab >> kDenShift;
+        tneg[i] = (uint32_t)(ab + ((1 << kDenShift) - 1)) >> kDenShift;
+        sb[i] = sign3(b[i]);
+    }
+    int32_t hi[4], lo[4];
+    hi[3] = 0;
+    lo[3] = 0;
+#pragma unroll
+    for (int i = 3; i > 0; i--) {
+        hi[i - 1] = (int32_t)__umul24(tpos[i], (uint32_t)L.wg[i]) + hi[i];
+        lo[i - 1] = lo[i] - (int32_t)__umul24(tneg[i], (uint32_t)L.wg[i]);
+    }
+    const int32_t totP = (int32_t)__umul24(tpos[0], (uint32_t)L.wg[0]) + hi[0];
+    const int32_t totM = lo[0] - (int32_t)__umul24(tneg[0], (uint32_t)L.wg[0]);
+    const int32_t cP = dpp_xor1(totP) & L.carryMask;
+    const int32_t cM = dpp_xor1(totM) & L.carryMask;
+
+    // dependent chain: out[j] = sext(del + top + ((denhalf - sum) >> 9)), -((256 - s) >> 9) == (s + 255) >> 9
+    int32_t s = L.c255;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;
+    s += dpp_xor1(s);
+    const int32_t out = __builtin_amdgcn_sbfe(del + tp - (s >> kDenShift), 0, chanbits);
+
+    // coefficient update, driven by del (dp_dec.c:143-188 == the encoder's walk)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int32_t e = med3_i32(del, lo[i] + cM, hi[i] + cP) - del;
+        a[i] = __mul24(sign3(e), sb[i]) + a[i];
+    }
+    // windows: lane 0's oldest sample moves to lane 1, the oldest sample of the last active tap is the next top
+    const int32_t x = dpp_xor1(w[3]) & L.feed;
+    tp = L.topMine ? w[3] : x;
+    w[3] = w[2];
+    w[2] = w[1];
+    w[1] = w[0];
+    w[0] = L.takeOut ? out : x;
+    return out;
+}
+
 }  // namespace alacdev
