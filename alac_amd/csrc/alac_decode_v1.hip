@@ -259,6 +259,159 @@ __global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
     }
 }
 
+// branch-free skip: the refill is a select, the look-ahead word is re-read every time (its latency is covered
+// by the symbols decoded before the next refill needs it)
+__device__ __forceinline__ void bw_skip_bf(BitWin &b, uint32_t n)  // n <= 32
+{
+    b.win <<= n;
+    b.have -= n;
+    b.pos += n;
+    const bool refill = b.have < 32;
+    const uint64_t add = (uint64_t)b.nw << ((32 - b.have) & 31);
+    b.win |= refill ? add : 0ull;
+    b.have += refill ? 32u : 0u;
+    b.idx += refill ? 1u : 0u;
+    b.nw = b.ring[(b.idx - b.org) & 31u];
+}
+
+// per-lane state of the entropy kernel
+struct EntLane {
+    BitWin bw;
+    uint32_t F;            // first word (relative to the packet's first staged word) not yet in the ring
+    uint32_t active;       // still decoding
+    uint32_t chan, c, mb, zmode, pb;
+    int32_t status;
+    int32_t *row;          // row of the channel being decoded
+};
+
+// The rounds of one wave.  PB40: every lane uses pb = 40 (pbFactor 4 with the standard cookie — every stream this
+// library or Apple's encoder writes), so pb * x is two shifts; otherwise full 32-bit multiplies.
+template <bool PB40>
+__device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, uint32_t *ringRow, uint64_t wordBase,
+                                               uint32_t cur0, uint32_t bit0, uint32_t limit, uint64_t nbytes,
+                                               uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV)
+{
+    const DecodeArgs &A = V.d;
+    const uint32_t wb = (1u << A.kb) - 1;
+    auto fetch16 = [&](uint32_t rel, uint32_t (&q)[16]) {
+        uint64_t w = wordBase + rel;
+        const uint64_t lastStart = V.capWords - kWinWords;  // corrupt input may run past the packet: stay inside
+        w = w < lastStart ? w : lastStart;
+        const uint32_t *sw = V.words + w;
+#pragma unroll
+        for (int i = 0; i < 16; i++) q[i] = sw[i];
+    };
+    auto write16 = [&](uint32_t rel, const uint32_t (&q)[16]) {
+        uint32_t *dst = ringRow + ((rel - cur0) & 31u);
+#pragma unroll
+        for (int i = 0; i < 16; i++) dst[i] = q[i];
+    };
+    auto mul_pb = [&](uint32_t x) { return PB40 ? (x << 5) + (x << 3) : E.pb * x; };
+
+    uint32_t q[16];
+    bool pending = false;
+    uint32_t pendBase = 0;
+    BitWin &bw = E.bw;
+    while (__any(E.active != 0)) {
+        if (pending) {
+            write16(pendBase, q);
+            E.F = pendBase + 16;
+            pending = false;
+        }
+        if (E.active && E.F - (bw.pos >> 5) <= 16) {
+            fetch16(E.F, q);
+            pending = true;
+            pendBase = E.F;
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < kDecRound; it++) {
+            if (E.active && E.F * 32 - bw.pos >= 160) {
+                // ---- one residual: dyn_get_32bit (ag_dec.c:220-270), straight-line for the common case ----
+                const uint32_t k = min(22u - (uint32_t)__builtin_clz(E.mb + (3u << kQBShift)), A.kb);  // lg3a(mb >> 9)
+                const uint32_t m = (1u << k) - 1;
+                const uint32_t stream = bw_peek(bw);
+                const uint32_t pre = (uint32_t)__builtin_clz(~stream | 1u);  // leading ones, at most 31
+                const uint32_t v = (stream << (pre + 1)) >> (32 - k);        // only meaningful below the escape
+                const uint32_t big = v >= 2 ? 1u : 0u;
+                uint32_t n = k != 1 ? pre * m + (big ? v - 1 : 0u) : pre;
+                uint32_t used = pre + 1 + (k != 1 ? k - 1 + big : 0u);
+                const bool lim = !(bw.pos < limit);  // ag_dec.c:302
+                const bool esc = pre >= kMaxPrefix;
+                if (__any(lim || esc)) {
+                    if (lim) {
+                        E.status = -50;
+                        E.active = 0;
+                        used = 0;
+                    } else if (esc) {
+                        bw_skip(bw, kMaxPrefix);
+                        n = bw_get(bw, chanBits);
+                        used = 0;
+                    }
+                }
+                bw_skip_bf(bw, used);
+                const uint32_t nd = n + E.zmode;
+                // ((nd + 1) >> 1) * (nd odd ? -1 : 1); stored even when the packet just failed (c < numSamples still)
+                E.row[E.c] = (int32_t)((nd >> 1) ^ (0u - (nd & 1u)));
+                E.c++;
+                uint32_t mb = mul_pb(nd) + E.mb - (mul_pb(E.mb) >> kQBShift);
+                mb = n > kMeanClamp ? kMeanClamp : mb;
+                E.mb = mb;
+                E.zmode = 0;
+                const bool zrun = ((mb << 2) < (1u << kQBShift)) && (E.c < numSamples) && E.active;
+                if (__any(zrun || E.c >= numSamples)) {
+                    if (zrun) {
+                        // zero run (ag_dec.c:324-352): the plane is pre-zeroed, only the index moves
+                        E.zmode = 1;
+                        const uint32_t kz = (uint32_t)(lead(mb) - 24 + (int32_t)((mb + 16u) >> 6));
+                        const uint32_t mz = ((1u << kz) - 1) & wb;
+                        const uint32_t st2 = bw_peek(bw);
+                        const uint32_t prz = (uint32_t)__builtin_clz(~st2 | 1u);
+                        uint32_t nz;
+                        if (prz >= kMaxPrefix) {
+                            nz = (st2 << kMaxPrefix) >> (32 - kMaxRunBits);
+                            bw_skip(bw, kMaxPrefix + kMaxRunBits);
+                        } else {
+                            const uint32_t vz = (st2 << (prz + 1)) >> (32 - kz);
+                            nz = prz * mz + vz - 1;
+                            uint32_t uz = prz + 1 + kz;
+                            if (vz < 2) {
+                                nz -= (vz - 1);
+                                uz -= 1;
+                            }
+                            bw_skip(bw, uz);
+                        }
+                        if (!((uint64_t)E.c + nz <= (uint64_t)numSamples)) {  // :341
+                            E.status = -50;
+                            E.active = 0;
+                        }
+                        E.c += nz;
+                        if (nz >= 65535) E.zmode = 0;
+                        E.mb = 0;
+                    }
+                    if (E.active && E.c >= numSamples) {
+                        // channel complete: ag_dec.c:359 end check; the next channel starts where this one ended
+                        if ((uint64_t)(bw.pos - bit0 + 7) / 8 > nbytes) {
+                            E.status = -50;
+                            E.active = 0;
+                        } else if (E.chan + 1 < ech) {
+                            E.chan++;
+                            E.c = 0;
+                            E.mb = A.mb;
+                            E.zmode = 0;
+                            E.pb = pbV;
+                            E.row += A.frameSize;
+                        } else {
+                            E.active = 0;
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
 {
     __shared__ uint32_t ring[64 * kWinStride];
@@ -269,170 +422,64 @@ __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
     const uint64_t off = live ? A.offsets[p] : 0;
     const uint64_t nbytes = live ? A.offsets[p + 1] - off : 0;
     DecRec *rec = A.recs + (live ? p : 0);
-    int32_t status = live ? rec->status : 0;
+    const int32_t status0 = live ? rec->status : 0;
     const uint32_t ech = live ? rec->elementChannels : 0;
     const uint32_t numSamples = live ? rec->numSamples : 0;
     const uint32_t chanBits = A.bitDepth - (live ? rec->bytesShifted : 0) * 8 + (ech == 2 ? 1 : 0);
     const uint32_t pbU = live ? (A.pb * rec->c[0].pbFactor) / 4 : A.pb;  // :825
     const uint32_t pbV = live ? (A.pb * rec->c[1].pbFactor) / 4 : A.pb;  // :841
-    const uint64_t hpos = live ? rec->pad : 0;
-    const bool coded = live && status == 0 && ech != 0 && !rec->escape && numSamples > 0;
+    const uint32_t hpos = live ? rec->pad : 0;
+    const bool coded = live && status0 == 0 && ech != 0 && !rec->escape && numSamples > 0;
 
-    // ---- payload: window reader over the staged words ----
-    // bit positions below are relative to the packet's first staged word (the packet starts at bit 8 * (off & 3))
+    // bit positions are relative to the packet's first staged word (the packet starts at bit 8 * (off & 3))
     const uint64_t wordBase = off >> 2;
     const uint32_t bit0 = (uint32_t)(off & 3) * 8;
     const uint32_t limit = bit0 + (uint32_t)nbytes * 8;  // maxPos of ag_dec.c:295
-    const uint32_t wb = (1u << A.kb) - 1;
-    int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
+    const uint32_t pos0 = bit0 + hpos;
+    const uint32_t cur0 = pos0 >> 5;
 
-    uint32_t state = coded ? kStGolomb : kStIdle;
-    uint32_t chan = 0;             // Golomb: channel being decoded
-    uint32_t c = 0;                // Golomb: sample index in the channel; raw: field index
-    uint32_t mb = A.mb, zmode = 0, pb = pbU;
-
-    // ---- circular ring of 32 staged words per lane; word t (relative to the lane's first payload word) lives in
+    // ---- circular ring of 32 staged words per lane; word t (relative to the packet's first staged word) lives in
     // slot (t - cur0) & 31.  16 words are fetched whenever 16 slots are free, one round (16 symbols) before they
     // are written into the ring, so the global latency is covered by the round's own work.
-    BitWin bw;
-    bw.ring = ring + lane * kWinStride;
-    const uint32_t pos0 = bit0 + (uint32_t)hpos;
-    const uint32_t cur0 = pos0 >> 5;
-    uint32_t F = cur0;  // first word not yet in the ring
-    auto fetch16 = [&](uint32_t rel, uint32_t (&q)[16]) {
-        uint64_t w = wordBase + rel;
-        const uint64_t lastStart = V.capWords - kWinWords;  // corrupt input may run past the packet: stay inside
+    uint32_t *ringRow = ring + lane * kWinStride;
+    EntLane E;
+    {
+        uint64_t w = wordBase + cur0;
+        const uint64_t lastStart = V.capWords - kWinWords;
         w = w < lastStart ? w : lastStart;
         const uint32_t *sw = V.words + w;
 #pragma unroll
-        for (int i = 0; i < 16; i++) q[i] = sw[i];
-    };
-    auto write16 = [&](uint32_t rel, const uint32_t (&q)[16]) {
-        uint32_t *dst = ring + lane * kWinStride + ((rel - cur0) & 31u);
-#pragma unroll
-        for (int i = 0; i < 16; i++) dst[i] = q[i];
-    };
-    uint32_t q[16];
-    fetch16(F, q);
-    write16(F, q);
-    F += 16;
-    bool pending = false;
-    uint32_t pendBase = 0;
+        for (int i = 0; i < 16; i++) ringRow[i] = sw[i];
+    }
+    asm volatile("" ::: "memory");
+    E.F = cur0 + 16;
     {
-        // prime the window at pos0
         const uint32_t sh = pos0 & 31;
-        bw.win = (((uint64_t)bw.ring[0] << 32) | bw.ring[1]) << sh;
-        bw.have = 64 - sh;
-        bw.idx = cur0 + 2;
-        bw.nw = bw.ring[2];
-        bw.pos = pos0;
-        bw.org = cur0;
+        E.bw.ring = ringRow;
+        E.bw.win = (((uint64_t)ringRow[0] << 32) | ringRow[1]) << sh;
+        E.bw.have = 64 - sh;
+        E.bw.idx = cur0 + 2;
+        E.bw.nw = ringRow[2];
+        E.bw.pos = pos0;
+        E.bw.org = cur0;
     }
+    E.active = coded ? 1u : 0u;
+    E.chan = 0;
+    E.c = 0;
+    E.mb = A.mb;
+    E.zmode = 0;
+    E.pb = pbU;
+    E.status = status0;
+    E.row = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
 
-    while (__any(state != kStIdle)) {
-        if (pending) {
-            write16(pendBase, q);
-            F = pendBase + 16;
-            pending = false;
-        }
-        if (state != kStIdle && F - (bw.pos >> 5) <= 16) {
-            fetch16(F, q);
-            pending = true;
-            pendBase = F;
-        }
-        asm volatile("" ::: "memory");
+    if (__all(!coded || (pbU == 40 && pbV == 40)))
+        entropy_rounds<true>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV);
+    else
+        entropy_rounds<false>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV);
 
-        for (int it = 0; it < kDecRound; it++) {
-            const bool room = F * 32 - bw.pos >= 160;
-            if (state == kStGolomb && room) {
-                if (!(bw.pos < limit)) {  // ag_dec.c:302
-                    status = -50;
-                    state = kStIdle;
-                } else {
-                    // one residual: dyn_get_32bit (ag_dec.c:220-270)
-                    uint32_t k = (uint32_t)lg3a(mb >> kQBShift);
-                    k = k > A.kb ? A.kb : k;
-                    const uint32_t m = (1u << k) - 1;
-                    uint32_t stream = bw_peek(bw);
-                    const uint32_t pre = (uint32_t)__builtin_clz(~stream | 1u);  // leading ones, at most 31
-                    uint32_t n;
-                    if (pre >= kMaxPrefix) {
-                        bw_skip(bw, kMaxPrefix);
-                        n = bw_get(bw, chanBits);
-                    } else {
-                        n = pre;
-                        uint32_t used = pre + 1;
-                        if (k != 1) {
-                            const uint32_t v = (stream << (pre + 1)) >> (32 - k);
-                            n = pre * m;
-                            used += k - 1;
-                            if (v >= 2) {
-                                n += v - 1;
-                                used += 1;
-                            }
-                        }
-                        bw_skip(bw, used);
-                    }
-                    const uint32_t nd = n + zmode;
-                    const int32_t mult = (-(int32_t)(nd & 1)) | 1;
-                    (rowU + chan * A.frameSize)[c] = (int32_t)((nd + 1) >> 1) * mult;
-                    c++;
-                    mb = pb * nd + mb - ((pb * mb) >> kQBShift);
-                    if (n > kMeanClamp) mb = kMeanClamp;
-                    zmode = 0;
-                    if (((mb << 2) < (1u << kQBShift)) && (c < numSamples)) {
-                        // zero run (ag_dec.c:324-352): the plane is pre-zeroed, only the index moves
-                        zmode = 1;
-                        const uint32_t kz = (uint32_t)(lead(mb) - 24 + (int32_t)((mb + 16u) >> 6));
-                        const uint32_t mz = ((1u << kz) - 1) & wb;
-                        stream = bw_peek(bw);
-                        const uint32_t prz = (uint32_t)__builtin_clz(~stream | 1u);
-                        uint32_t nz;
-                        if (prz >= kMaxPrefix) {
-                            nz = (stream << kMaxPrefix) >> (32 - kMaxRunBits);
-                            bw_skip(bw, kMaxPrefix + kMaxRunBits);
-                        } else {
-                            const uint32_t v = (stream << (prz + 1)) >> (32 - kz);
-                            nz = prz * mz + v - 1;
-                            uint32_t used = prz + 1 + kz;
-                            if (v < 2) {
-                                nz -= (v - 1);
-                                used -= 1;
-                            }
-                            bw_skip(bw, used);
-                        }
-                        if (!((uint64_t)c + nz <= (uint64_t)numSamples)) {  // :341
-                            status = -50;
-                            state = kStIdle;
-                        }
-                        c += nz;
-                        if (nz >= 65535) zmode = 0;
-                        mb = 0;
-                    }
-                    if (state != kStIdle && c >= numSamples) {
-                        // channel complete: ag_dec.c:359 end check, then the next channel starts where this one ended
-                        if ((uint64_t)(bw.pos - bit0 + 7) / 8 > nbytes) {
-                            status = -50;
-                            state = kStIdle;
-                        } else if (chan + 1 < ech) {
-                            chan++;
-                            c = 0;
-                            mb = A.mb;
-                            zmode = 0;
-                            pb = pbV;
-                        } else {
-                            state = kStIdle;
-                        }
-                    }
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-    }
-
-    if (live && status != rec->status) {
-        rec->status = status;
-        A.statusOut[p] = status;
+    if (live && E.status != status0) {
+        rec->status = E.status;
+        A.statusOut[p] = E.status;
         A.numSamplesOut[p] = 0;
     }
 }

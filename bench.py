@@ -49,6 +49,18 @@ def cpu_baseline(fmt, pcm_host, packets, gpu_stream=None, gpu_sizes=None):
                        f"oracle/alac_oracle.c -O2 single thread, {dt:.2f} s"), exact
 
 
+def cpu_all_cores(fmt, packets):
+    """The same CPU port on every host core at once (tools/cpu_all_cores.py: one worker process per core, run as
+    a child process so that nothing here forks after the GPU is initialised).  SURVEY.md §8d."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), str(packets), str(fmt.bit_depth)],
+                           capture_output=True, text=True, timeout=300)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:  # the headline does not depend on it
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +69,7 @@ def main():
     ap.add_argument("--packets", type=int, default=10000, help="packets per GPU per step (configs[1] = 10000)")
     ap.add_argument("--bit-depth", type=int, default=16)
     ap.add_argument("--cpu-packets", type=int, default=10000, help="size of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode-direction measurement (N = 1)")
     ap.add_argument("--no-reassemble", action="store_true", help="skip the RCCL re-assembly at N > 1")
     ap.add_argument("--force-reassemble", action="store_true",
                     help="rehearsal: run the RCCL re-assembly path even with one rank (needs torch.distributed.run)")
@@ -216,6 +229,21 @@ def main():
                          "note": "dominant stage by measured time; the path is bound by serial integer "
                                  "recurrences (sign-LMS, Golomb mean tracker), not by HBM"},
         }
+        if world == 1 and not args.no_decode:
+            # decode direction (BASELINE configs[4]), reported beside the headline: the packed stream of the last
+            # step back to PCM, round trip checked against the generator output
+            cookie = ctx.magic_cookie(fmt)
+            reps = max(3, min(args.steps, 10))
+            ctx.decode(cookie, last["out"], last["offsets"], B)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                d_out, d_ns, d_st, _ = ctx.decode(cookie, last["out"], last["offsets"], B)
+            ctx.synchronize()
+            ddt = (time.perf_counter() - t1) / reps
+            out["decode"] = {"ms_per_step": round(ddt * 1e3, 4), "value": round(B * fmt.frame_size / ddt / 1e6, 1),
+                             "unit": "Msamples/s", "steps": reps,
+                             "round_trip_exact": bool(torch.equal(d_out, d_pcm)) and int(d_st.abs().sum()) == 0}
         if world == 1 and args.cpu_packets > 0:
             n = min(args.cpu_packets, B)
             g_stream = last["out"][:total_bytes].cpu().numpy()
@@ -224,6 +252,7 @@ def main():
             out["cpu_baseline"] = base
             out["bit_exact_vs_cpu"] = exact
             out["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
+            out["cpu_all_cores"] = cpu_all_cores(fmt, n)
         print(json.dumps(out), flush=True)
     if rank == 0 and use_dist and not args.no_reassemble and gather is not None:
         # the re-assembled stream on this rank must be the rank-ordered concatenation; rank 0's own shard leads it
