@@ -28,14 +28,15 @@ constexpr int kWinWords = 16;    // words staged per lane per round (64 bytes)
 constexpr int kWinStride = 33;   // LDS words per lane: a circular ring of 32 (+1: odd stride, conflict-free columns)
 
 // ---- k_dec_stage ---------------------------------------------------------------------------------
-// words[i] = bytes 4i .. 4i+3 of the stream as one MSB-first word; zeros from the end of the stream to `capWords`
+// words[i] = bytes 4i .. 4i+3 of the stream as one MSB-first word, followed by 64 words of zeros
 __global__ __launch_bounds__(256) void k_dec_stage(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets,
                                                    uint32_t *words, uint64_t capWords)
 {
     const uint64_t total = offsets[numPackets];
     const uint64_t fullWords = total >> 2;
     const bool aligned = ((uintptr_t)stream & 3) == 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capWords; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t endWords = min(capWords, ((total + 3) >> 2) + 64);  // the readers never go past this (dec_word_limit)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < endWords; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t v = 0;
         if (i < fullWords && aligned) {
             v = __builtin_bswap32(((const uint32_t *)stream)[i]);
@@ -293,9 +294,10 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
 {
     const DecodeArgs &A = V.d;
     const uint32_t wb = (1u << A.kb) - 1;
+    const uint64_t wordLimit = min(V.capWords, ((A.offsets[A.numPackets] + 3) >> 2) + 64);  // what k_dec_stage wrote
     auto fetch16 = [&](uint32_t rel, uint32_t (&q)[16]) {
         uint64_t w = wordBase + rel;
-        const uint64_t lastStart = V.capWords - kWinWords;  // corrupt input may run past the packet: stay inside
+        const uint64_t lastStart = wordLimit - kWinWords;  // corrupt input may run past the packet: stay inside
         w = w < lastStart ? w : lastStart;
         const uint32_t *sw = V.words + w;
 #pragma unroll
@@ -442,10 +444,11 @@ __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
     // slot (t - cur0) & 31.  16 words are fetched whenever 16 slots are free, one round (16 symbols) before they
     // are written into the ring, so the global latency is covered by the round's own work.
     uint32_t *ringRow = ring + lane * kWinStride;
+    const uint64_t wordLimit = min(V.capWords, ((A.offsets[A.numPackets] + 3) >> 2) + 64);
     EntLane E;
     {
         uint64_t w = wordBase + cur0;
-        const uint64_t lastStart = V.capWords - kWinWords;
+        const uint64_t lastStart = wordLimit - kWinWords;
         w = w < lastStart ? w : lastStart;
         const uint32_t *sw = V.words + w;
 #pragma unroll
