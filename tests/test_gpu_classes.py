@@ -1,0 +1,36 @@
+"""The drop-in C++ classes driven with the reference tool's own call sequence (tests/cpp/fork_calls.hip mirrors
+convert-utility/main.cu's EncodeALAC / DecodeALAC): device buffer -> InitializeSampling -> Encode(index), and
+Decode(index) -> fillWriteBuffer.  Output must equal the oracle's chained encode and decode back to the input."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from container_lib import music_like
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+@pytest.fixture(scope="module")
+def harness(gpu_ctx):
+    subprocess.check_call(["make", "-C", CPP, "fork_calls"], stdout=subprocess.DEVNULL)
+    return os.path.join(CPP, "fork_calls")
+
+
+@pytest.mark.parametrize("bits,ch,frames", [(16, 2, 4096 * 5 + 321), (16, 1, 4096 * 2 + 7), (24, 2, 4096 * 2), (32, 2, 4096 + 100)])
+def test_reference_call_sequence(harness, oracle, tmp_path, bits, ch, frames):
+    pcm = music_like(frames, ch, bits, seed=bits + ch)
+    (tmp_path / "in.pcm").write_bytes(pcm)
+    p = subprocess.run([harness, str(bits), str(ch), "44100", str(tmp_path / "in.pcm"), str(tmp_path / "s.bin"),
+                        str(tmp_path / "z.bin"), str(tmp_path / "back.pcm")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    enc = oracle.encoder(4096, bits, ch, 44100)
+    ref, ref_sizes = enc.encode_stream(np.frombuffer(pcm, np.uint8), frames, segment_packets=0)  # chained, as one file
+    got = np.fromfile(tmp_path / "s.bin", np.uint8)
+    got_sizes = np.fromfile(tmp_path / "z.bin", np.uint32)
+    assert np.array_equal(got_sizes, ref_sizes)
+    assert np.array_equal(got, ref)
+    assert (tmp_path / "back.pcm").read_bytes() == pcm
