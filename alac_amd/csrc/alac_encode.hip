@@ -569,8 +569,33 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
             for (uint32_t w = sp.w0 + threadIdx.x; w < sp.w1; w += blockDim.x) one(w);
         }
     };
-    Span spU = {0, 0}, spV = {0, 0}, spR = {0, 0};
+    Span spU = {0, 0}, spV = {0, 0}, spR = {0, 0}, spS = {0, 0};
     if (!rec.escape) {
+        if constexpr (SHB != 0 && (DEPTH == 24 || DEPTH == 32)) {
+            // shift-off bytes (codec/ALACEncoder.cu:489-503): the low SHB bytes of every channel sample, MSB first.
+            // 24-bit: one byte per 3-byte sample, four samples (three PCM dwords) per output word;
+            // 32-bit: two bytes per sample, two samples (two PCM dwords) per output word.
+            spS = span_of(offShift, lenShift);
+            const uint32_t *pw = (const uint32_t *)pk;  // packets are dword aligned for these depths (frame * 6 or 8 bytes)
+            const uint32_t fields = N * CH;             // samples; the last word may hold fewer than a full group
+            copy_span(spS, offShift, [&](uint32_t i) -> uint32_t {
+                if constexpr (DEPTH == 24) {
+                    const uint32_t t = 4 * i;
+                    if (t + 4 <= fields) {
+                        const uint32_t w0 = pw[3 * i], w1 = pw[3 * i + 1], w2 = pw[3 * i + 2];
+                        return (w0 << 24) | ((w0 >> 24) << 16) | (((w1 >> 16) & 0xffu) << 8) | ((w2 >> 8) & 0xffu);
+                    }
+                    uint32_t v = 0;
+                    for (uint32_t q = 0; q < 4; q++)
+                        v = (v << 8) | (t + q < fields ? ((uint32_t)load_sample<24>(pk, t + q) & 0xffu) : 0u);
+                    return v;
+                } else {
+                    const uint32_t t = 2 * i;
+                    const uint32_t a = t < fields ? pw[t] : 0u, b = t + 1 < fields ? pw[t + 1] : 0u;
+                    return (a << 16) | (b & 0xffffu);
+                }
+            });
+        }
         spU = span_of(offU, lenU);
         copy_span(spU, offU, [&](uint32_t i) { return wU[i]; });
         if constexpr (CH == 2) {
@@ -589,7 +614,9 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
 
     __syncthreads();  // header words complete
     for (uint32_t aw = threadIdx.x; aw < nwords; aw += blockDim.x) {
-        if ((aw >= spU.w0 && aw < spU.w1) || (aw >= spV.w0 && aw < spV.w1) || (aw >= spR.w0 && aw < spR.w1)) continue;
+        if ((aw >= spU.w0 && aw < spU.w1) || (aw >= spV.w0 && aw < spV.w1) || (aw >= spR.w0 && aw < spR.w1) ||
+            (aw >= spS.w0 && aw < spS.w1))
+            continue;
         const int64_t bp = (int64_t)aw * 32 - (int64_t)mis * 8;
         uint32_t v = take([&](uint64_t s0) { return words_fetch32(hdr, (uint32_t)lenHdr, (uint32_t)s0); }, lenHdr, bp);
         if (!rec.escape) {

@@ -18,12 +18,24 @@
 //
 // Reference control flow: codec/ALACEncoder.cu:290-558 (EncodeStereo), :812-963 (EncodeMono).
 #include <cstdlib>
+#include <type_traits>
 #include "alac_dev.hpp"
 #include "alac_kernels.hpp"
 #include "alac_lms.hpp"
 #include "alac_golomb.hpp"
 
 namespace alacdev {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (indices that MUST fold, e.g. into
+// register-array subscripts, cannot be left to the unroller)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 
 constexpr int kTile = 64;         // predictor steps per LDS tile
 constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; 12 keeps
@@ -145,40 +157,87 @@ struct StageRegs {
     static constexpr int SLOTS = 64 / LPC;
     static constexpr int TASKS = (SLOTS / CH) * (kRowLen / 4);  // (packet, 4-sample group) pairs
     static constexpr int ITERS = (TASKS + 63) / 64;
-    int32_t v[ITERS][4];  // raw PCM words of each task (16-bit: 4 stereo frames / 2 mono pairs; else unused)
+    int32_t v[ITERS][9];  // raw PCM dwords of each task: 4 sample-frames = CH * bytes-per-sample dwords (<= 8), +1 spare
 };
+
+// channel-sample s (0 .. 4 CH - 1) of a task's dwords, after the shift-off of the low bytes — what load_lr /
+// load_sample >> SH deliver (codec/matrix_enc.cu:79-82, :129-134, :197-202, :338-342); s is a compile-time
+// constant wherever this is called, so everything folds to one or two shifts
+template <int DEPTH, int S>
+__device__ __forceinline__ int32_t task_sample(const int32_t (&w)[9])
+{
+    if constexpr (DEPTH == 16) {
+        return (S & 1) ? (w[S >> 1] >> 16) : (int32_t)(int16_t)w[S >> 1];
+    } else if constexpr (DEPTH == 32) {
+        return w[S] >> 16;  // bytesShifted = 2
+    } else {
+        constexpr int o = 3 * S, i = o >> 2, shb = (o & 3) * 8;
+        const uint32_t lo = (uint32_t)w[i], hi = (uint32_t)w[i + 1];
+        // the 3 bytes at byte offset o, left aligned in a dword
+        uint32_t x;
+        if constexpr (shb == 0) x = lo << 8;
+        else if constexpr (shb == 8) x = lo & 0xffffff00u;
+        else x = ((hi << (32 - shb)) | (lo >> shb)) << 8;
+        return DEPTH == 20 ? ((int32_t)x >> 12) : ((int32_t)x >> 16);  // 20: full value; 24: >> 8 (bytesShifted = 1)
+    }
+}
+
+// vector width of a task's loads: the PCM base is 16-byte aligned, so the packet stride decides whether they apply
+template <int DEPTH, int CH>
+__device__ __forceinline__ bool task_vec_ok(uint32_t frameBytes)
+{
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+    constexpr uint32_t ALIGN = (BPF == 4 || BPF == 8) ? 16 : ((BPF & 1) == 0 ? 8 : 4);
+    return (frameBytes & (ALIGN - 1)) == 0;
+}
+
+// the BPF dwords of one task (4 sample-frames) starting at src
+template <int DEPTH, int CH>
+__device__ __forceinline__ void task_load(const uint8_t *src, int32_t (&w)[9])
+{
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);  // bytes per sample-frame = dwords per 4-frame task
+    if constexpr (BPF == 4) {  // 16-bit stereo: the task is 16 bytes, 16-byte aligned
+        const int4 w4 = *(const int4 *)src;
+        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+    } else if constexpr (BPF == 8) {  // 32-bit stereo: 32 bytes, 16-byte aligned
+        const int4 a4 = ((const int4 *)src)[0], b4 = ((const int4 *)src)[1];
+        w[0] = a4.x; w[1] = a4.y; w[2] = a4.z; w[3] = a4.w;
+        w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
+    } else if constexpr ((BPF & 1) == 0) {  // 8-byte aligned tasks: 16-bit mono (8 B), 20/24-bit stereo (24 B)
+#pragma unroll
+        for (int k = 0; k < BPF; k += 2) {
+            const int2 w2 = ((const int2 *)src)[k >> 1];
+            w[k] = w2.x;
+            w[k + 1] = w2.y;
+        }
+    } else {  // 20/24-bit mono: 12 bytes, dword aligned
+#pragma unroll
+        for (int k = 0; k < BPF; k++) w[k] = ((const int32_t *)src)[k];
+    }
+    w[BPF] = 0;  // task_sample's over-read of the last 3-byte sample
+}
 
 template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_load(StageRegs<CH, LPC> &R, const LmsShared<LPC> &sh, const uint8_t *pcm,
                                            uint32_t frameBytes, int j0, int lane)
 {
     constexpr int GROUPS = kRowLen / 4;
-    if constexpr (DEPTH == 16) {
-        const bool vec = CH == 2 ? (frameBytes & 15) == 0 : (frameBytes & 7) == 0;
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+    const bool vec = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
-        for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
-            const int idx = it * 64 + lane;
-            const int q = idx / GROUPS, grp = idx - q * GROUPS;
-            const int row = q * CH;
-            R.v[it][0] = R.v[it][1] = R.v[it][2] = R.v[it][3] = 0;
-            if (idx < StageRegs<CH, LPC>::TASKS && vec) {
-                const uint32_t N = sh.pktN[row];
-                const int jb = j0 - kHist + grp * 4;
-                if (jb >= 0 && jb < (int)N) {
-                    const uint8_t *pk = pcm + (uint64_t)sh.pktIdx[row] * frameBytes;
-                    if constexpr (CH == 2) {
-                        const int4 w4 = *(const int4 *)(pk + (uint64_t)jb * 4);
-                        R.v[it][0] = w4.x;
-                        R.v[it][1] = w4.y;
-                        R.v[it][2] = w4.z;
-                        R.v[it][3] = w4.w;
-                    } else {
-                        const int2 w2 = *(const int2 *)(pk + (uint64_t)jb * 2);
-                        R.v[it][0] = w2.x;
-                        R.v[it][1] = w2.y;
-                    }
-                }
-            }
+    for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
+        const int idx = it * 64 + lane;
+        const int q = idx / GROUPS, grp = idx - q * GROUPS;
+        const int row = q * CH;
+#pragma unroll
+        for (int k = 0; k <= BPF; k++) R.v[it][k] = 0;
+        if (idx < StageRegs<CH, LPC>::TASKS && vec) {
+            const uint32_t N = sh.pktN[row];
+            const int jb = j0 - kHist + grp * 4;
+            // a group that starts inside the packet is loaded whole: its tail may lie past N but never past the
+            // packet's full-size slot in the PCM buffer
+            if (jb >= 0 && jb < (int)N)
+                task_load<DEPTH, CH>(pcm + (uint64_t)sh.pktIdx[row] * frameBytes + (uint64_t)jb * BPF, R.v[it]);
         }
     }
 }
@@ -189,7 +248,7 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
 {
     constexpr int GROUPS = kRowLen / 4;
     constexpr int SH = 8 * (int)bytes_shifted(DEPTH);
-    const bool vec = DEPTH == 16 && (CH == 2 ? (frameBytes & 15) == 0 : (frameBytes & 7) == 0);
+    const bool vec = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
     for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
         const int idx = it * 64 + lane;
@@ -202,19 +261,19 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
         int32_t u[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
         if (jb >= 0 && jb < (int)N) {
             if (vec) {
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
+                static_for<4>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
                     const bool in = jb + t < (int)N;
                     if constexpr (CH == 2) {
-                        const int32_t l = (int16_t)R.v[it][t], r = R.v[it][t] >> 16;
+                        const int32_t l = task_sample<DEPTH, 2 * t>(R.v[it]), r = task_sample<DEPTH, 2 * t + 1>(R.v[it]);
                         u[t] = in ? mix_sample(mixres, 0, l, r) : 0;
                         v[t] = in ? mix_sample(mixres, 1, l, r) : 0;
                     } else {
-                        const int32_t w = R.v[it][t >> 1];
-                        u[t] = in ? ((t & 1) ? (w >> 16) : (int32_t)(int16_t)w) : 0;
+                        u[t] = in ? task_sample<DEPTH, t>(R.v[it]) : 0;
                     }
-                }
+                });
             } else {
+                // packets that are not vector aligned (odd frame sizes): sample by sample
                 const uint8_t *pk = pcm + (uint64_t)sh.pktIdx[row] * frameBytes;
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
@@ -239,16 +298,16 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
     }
 }
 
-// ---- interior fast path of the staging (16-bit PCM, tile and its history fully inside every packet of the
+// ---- interior fast path of the staging (tile and its history fully inside every packet of the
 // wave): everything that does not change from tile to tile is computed once per pass, and a tile costs one
-// 16-byte (stereo) / 8-byte (mono) load plus the mix and the LDS writes per task — no bounds checks, no branches.
+// few vector loads plus the mix and the LDS writes per task — no bounds checks, no branches.
 template <int CH, int LPC>
 struct StagePlan {
     static constexpr int ITERS = StageRegs<CH, LPC>::ITERS;
     const uint8_t *pk[ITERS];  // address of the task's 4 sample-frames when the tile starts at j0 = kHist
     int xs[ITERS];             // LDS cell of the task's first u (v follows one row further)
     int32_t wl[ITERS], wr[ITERS], vsel[ITERS];  // u = (wl l + wr r) >> 2; v = vsel ? l - r : r
-    bool usable;               // 16-bit, vector-aligned frames
+    bool usable;               // dword-aligned packets
 };
 
 template <int DEPTH, int CH, int LPC>
@@ -256,13 +315,14 @@ __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShare
                                            uint32_t frameBytes, int lane)
 {
     constexpr int GROUPS = kRowLen / 4;
-    P.usable = DEPTH == 16 && (CH == 2 ? (frameBytes & 15) == 0 : (frameBytes & 7) == 0);
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);  // bytes per sample-frame = dwords per 4-frame task
+    P.usable = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
     for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
         const int idx = it * 64 + lane;
         const int q = idx / GROUPS, grp = idx - q * GROUPS;
         const int row = q * CH;
-        P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * CH * 2);
+        P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * BPF);
         P.xs[it] = row * kXsStride + grp * 4;
         const int32_t r = CH == 2 ? sh.rowMix[row] : 0;
         P.wl[it] = r ? r : (1 << kMixBits);
@@ -271,44 +331,32 @@ __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShare
     }
 }
 
-template <int CH, int LPC>
+template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_load_fast(StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P, int j0)
 {
-    const int64_t byteOff = (int64_t)(j0 - kHist) * (CH * 2);
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+    const int64_t byteOff = (int64_t)(j0 - kHist) * BPF;
 #pragma unroll
-    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
-        if constexpr (CH == 2) {
-            const int4 w4 = *(const int4 *)(P.pk[it] + byteOff);
-            R.v[it][0] = w4.x;
-            R.v[it][1] = w4.y;
-            R.v[it][2] = w4.z;
-            R.v[it][3] = w4.w;
-        } else {
-            const int2 w2 = *(const int2 *)(P.pk[it] + byteOff);
-            R.v[it][0] = w2.x;
-            R.v[it][1] = w2.y;
-        }
-    }
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
 }
 
-template <int CH, int LPC>
+template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_store_fast(const StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P,
                                                  LmsShared<LPC> &sh)
 {
 #pragma unroll
     for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
+        static_for<4>([&](auto T) {
+            constexpr int t = decltype(T)::value;
             if constexpr (CH == 2) {
-                const int32_t l = (int16_t)R.v[it][t], r = R.v[it][t] >> 16;
+                const int32_t l = task_sample<DEPTH, 2 * t>(R.v[it]), r = task_sample<DEPTH, 2 * t + 1>(R.v[it]);
                 // codec/matrix_enc.cu:72-99 with the mixRes = 0 case folded into the weights (4 l >> 2 == l)
                 sh.xs[P.xs[it] + t] = (__mul24(P.wl[it], l) + __mul24(P.wr[it], r)) >> kMixBits;
                 sh.xs[P.xs[it] + kXsStride + t] = P.vsel[it] ? l - r : r;
             } else {
-                const int32_t w = R.v[it][t >> 1];
-                sh.xs[P.xs[it] + t] = (t & 1) ? (w >> 16) : (int32_t)(int16_t)w;
+                sh.xs[P.xs[it] + t] = task_sample<DEPTH, t>(R.v[it]);
             }
-        }
+        });
     }
 }
 
@@ -431,7 +479,7 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     for (int j0 = 0; j0 < (int)runTo; j0 += kTile) {
         const bool more = j0 + kTile < (int)runTo;
         const bool fastNext = more && interior(j0 + kTile);
-        if (fastNext) stage_load_fast<CH, LPC>(R, SP, j0 + kTile);  // in flight under the tile
+        if (fastNext) stage_load_fast<DEPTH, CH, LPC>(R, SP, j0 + kTile);  // in flight under the tile
         else if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
         lds_order();
         const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
@@ -471,7 +519,7 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
             if (flag && ((((j0 / kTile) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + kTile, (int)runTo), lane, (A.pubMask >> 31) != 0);
         }
         lds_order();
-        if (fastNext) stage_store_fast<CH, LPC>(R, SP, sh);
+        if (fastNext) stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
         else if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
     }
 }
