@@ -610,6 +610,25 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
             const uint32_t x = pw[i];
             return (x << 16) | (x >> 16);
         });
+    } else if constexpr (DEPTH == 32) {
+        // raw 32-bit samples, MSB first: the word IS the little-endian sample
+        spR = span_of(offRaw, lenRaw);
+        const uint32_t *pw = (const uint32_t *)pk;
+        copy_span(spR, offRaw, [&](uint32_t i) { return pw[i]; });
+    } else if constexpr (DEPTH == 24) {
+        // raw 24-bit samples, MSB first: four samples (PCM bytes B0..B11 in three dwords) make three words
+        // B2 B1 B0 B5 | B4 B3 B8 B7 | B6 B11 B10 B9
+        spR = span_of(offRaw, lenRaw);
+        const uint32_t *pw = (const uint32_t *)pk;
+        const uint32_t ndw = (N * CH * 3 + 3) / 4;  // dwords that hold samples (the tail of the last one is padding)
+        copy_span(spR, offRaw, [&](uint32_t i) -> uint32_t {
+            const uint32_t g = i / 3, r = i - 3 * g;
+            const uint32_t d0 = 3 * g < ndw ? pw[3 * g] : 0u, d1 = 3 * g + 1 < ndw ? pw[3 * g + 1] : 0u,
+                           d2 = 3 * g + 2 < ndw ? pw[3 * g + 2] : 0u;
+            if (r == 0) return ((d0 << 8) & 0xff000000u) | ((d0 << 8) & 0x00ff0000u) | ((d0 << 8) & 0x0000ff00u) | ((d1 >> 8) & 0xffu);
+            if (r == 1) return (d1 << 24) | ((d0 >> 24) << 16) | ((d2 & 0xffu) << 8) | (d1 >> 24);
+            return (((d1 >> 16) & 0xffu) << 24) | ((d2 >> 24) << 16) | (((d2 >> 16) & 0xffu) << 8) | ((d2 >> 8) & 0xffu);
+        });
     }
 
     __syncthreads();  // header words complete
