@@ -56,3 +56,14 @@ def test_host_only_entry_points():
     wrapped = bytes(4) + b"frma" + b"alac" + bytes(4) + b"alac" + bytes(4) + bytes(ck)
     arr = (ctypes.c_uint8 * len(wrapped)).from_buffer_copy(wrapped)
     assert lib.alac_hip_format_from_cookie(arr, len(wrapped), ctypes.byref(back)) == 0 and back.bit_depth == 16
+
+
+def test_reference_stage_prototypes_are_exported():
+    """include/alac/dplib.h and aglib.h: the reference's own host-callable stage symbols (codec/dplib.h:49-55,
+    codec/aglib.h:70-74) resolve in the library."""
+    import ctypes
+    import alac_amd
+    lib = ctypes.CDLL(alac_amd.LIB_PATH)
+    for name in ("init_coefs", "copy_coefs", "pc_block", "unpc_block", "set_ag_params", "set_standard_ag_params",
+                 "dyn_comp", "dyn_decomp"):
+        assert getattr(lib, name) is not None
