@@ -672,7 +672,7 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
     const uint64_t stride = 5ull * A.chainsPad;
     GolF g;
     golf_reset(g);
-    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; });
+    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, one_plane(plane, stride, chain));
     if (active) A.bits1[t] = g.bits;
 }
 
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = r << 16;
-        golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; }, wait);
+        golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, one_plane(plane, stride, chain), wait);
         if (active) A.bits1[t] = g.bits;
     }
 }
@@ -771,13 +771,16 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
     const uint32_t nMax = wave_max(n8);
     const uint32_t p2lo = wave_min_u32(active ? P2 : 0xffffffffu), p2hi = wave_max(active ? P2 : 0u);
     if (CH == 1 || p2lo >= p2hi) {
-        const uint32_t P2u = CH == 1 ? 0xffffffffu : p2hi;
-        golf_stream<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
-            const int32_t *row = j < P2u ? planeB + j * strideB : planeA + j * strideA;
-            return row[chain];
-        });
+        RowSrc rs2;
+        rs2.p0 = planeB;
+        rs2.s0 = strideB;
+        rs2.p1 = planeA;
+        rs2.s1 = strideA;
+        rs2.split = CH == 1 ? 0xffffffffu : p2hi;
+        rs2.col = chain;
+        golf_stream<false>(g, n8, nMax, chanBits, recip, rs2);
     } else {
-        golf_stream<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
+        golf_stream_fn<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
             const int32_t b = (planeB + j * strideB)[chain], a = (planeA + j * strideA)[chain];
             return j < P2 ? b : a;
         });
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     golf_reset(g);
     g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
     g.wleft = A.wcap - 1;
-    golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; });
+    golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain));
     golf_flush<true>(g);
     if (active) rec->c[c].bits = g.bits;
 }
@@ -898,7 +901,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = 0;
-        golf_stream<true>(g, n, wave_max(n), chanBits, recip, [&](uint32_t j) { return (plane + j * stride)[chain]; }, wait);
+        golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait);
         golf_flush<true>(g);
         if (active) rec->c[c].bits = g.bits;
     }

@@ -105,27 +105,27 @@ __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
 template <bool WRITE, bool CHECKED>
 __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint32_t bitSize, const uint32_t *recip)
 {
-    if constexpr (!CHECKED) valid = true;
-    // (A) ag_enc.c:333-349
-    const bool inrun = valid && g.inrun;
-    const bool swallow = inrun && (del == 0);
-    g.nz += swallow ? 1u : 0u;
-    const bool cap = swallow && (g.nz >= 65535);
-    const bool close = inrun && (!swallow || cap);
+    // (A) ag_enc.c:333-349, on 0/1 flags in vector registers (boolean chains through scalar masks cost a lone
+    // wave three times as many instructions): del == 0 <=> its zig-zag image is 0
+    const uint32_t t2 = ((uint32_t)del << 1) ^ (uint32_t)(del >> 31);  // n + zmode = 2|del| - (del < 0)
+    const uint32_t nzf = min(t2, 1u);                                  // del != 0
+    const uint32_t inr = CHECKED ? (valid ? g.inrun : 0u) : g.inrun;
+    const uint32_t sw = inr & (nzf ^ 1u);                              // a zero swallowed by the open run
+    g.nz += sw;
+    const uint32_t capf = sw & ((g.nz + 1u) >> 16);                    // the run just reached 65535
+    const uint32_t cl = inr & (nzf | capf);                            // the run ends before / at this residual
     // (B)
-    if (__any(close)) {
-        if (close) {
+    if (__any(cl != 0)) {
+        if (cl) {
             golf_close_run<WRITE>(g, recip);
-            if (cap) g.zmode = 0;
+            if (capf) g.zmode = 0;
         }
     }
     // (C) ag_enc.c:285-331
-    if (valid && !swallow) {
+    if (CHECKED ? (valid && !sw) : !sw) {
         // k = min(lg3a(mb >> 9), kb); lg3a(x) = 31 - clz(x + 3) and clz((mb >> 9) + 3) = clz(mb + 1536) + 9
         const uint32_t k = min(22u - (uint32_t)__builtin_clz(g.mb + (3u << kQBShift)), kKB0);
         const uint32_t m = (1u << k) - 1;
-        // n + zmode = 2|del| - (del < 0): the zig-zag map
-        const uint32_t t2 = ((uint32_t)del << 1) ^ (uint32_t)(del >> 31);
         const uint32_t n = t2 - g.zmode;
         const bool esc = n >= m * 9;  // div >= MAX_PREFIX_32
         // n / m for m = 2^k - 1, needed only when n < 9 m.  With n = q0 2^k + r0 = q0 m + (q0 + r0) and
@@ -191,8 +191,79 @@ struct NoWait {
     __device__ __forceinline__ void operator()(uint32_t) const {}
 };
 
-template <bool WRITE, class Fetch, class Need = NoWait>
+// Row source of golf_stream: rows below `split` come from plane p0 (row stride s0 elements), the rest from p1/s1;
+// the lane reads column `col` of a row.  Row addresses are scalar and advance by one add per row (no multiply).
+struct RowSrc {
+    const int32_t *p0, *p1;
+    uint64_t s0, s1;
+    uint32_t split;  // 0xffffffff: single plane p0
+    uint32_t col;
+};
+
+__device__ __forceinline__ RowSrc one_plane(const int32_t *plane, uint64_t stride, uint32_t col)
+{
+    RowSrc r;
+    r.p0 = r.p1 = plane;
+    r.s0 = r.s1 = stride;
+    r.split = 0xffffffffu;
+    r.col = col;
+    return r;
+}
+
+template <bool WRITE, class Need = NoWait>
 __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
+                                            const uint32_t *recip, const RowSrc &R, Need &&need = Need())
+{
+    constexpr int B = 16;
+    int32_t bufA[B], bufB[B], bufC[B];
+    auto load = [&](int32_t (&buf)[B], uint32_t jb) {
+        if (jb < nMaxWave) {
+            need(min(jb + B, nMaxWave));
+            if (jb + B <= R.split || jb >= R.split) {
+                const bool first = jb + B <= R.split;
+                const uint64_t st = first ? R.s0 : R.s1;
+                const int32_t *row = (first ? R.p0 : R.p1) + (uint64_t)jb * st;
+#pragma unroll
+                for (int s = 0; s < B; s++) {
+                    buf[s] = row[R.col];
+                    row += st;
+                }
+            } else {  // the block straddles the split (never with 4096-sample packets: split = 128)
+#pragma unroll
+                for (int s = 0; s < B; s++) {
+                    const uint32_t j = jb + s;
+                    buf[s] = (j < R.split ? R.p0 + (uint64_t)j * R.s0 : R.p1 + (uint64_t)j * R.s1)[R.col];
+                }
+            }
+        }
+    };
+    const uint32_t nMinWave = wave_min_u32(n);
+    auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
+        if (jb >= nMaxWave) return;
+        if (jb + B <= nMinWave) {  // every lane owns the whole block
+#pragma unroll
+            for (int s = 0; s < B; s++) golf_sym<WRITE, false>(g, buf[s], true, bitSize, recip);
+        } else {
+#pragma unroll
+            for (int s = 0; s < B; s++) golf_sym<WRITE, true>(g, buf[s], jb + s < n, bitSize, recip);
+        }
+    };
+    load(bufA, 0);
+    load(bufB, B);
+    for (uint32_t jb = 0; jb < nMaxWave; jb += 3 * B) {
+        load(bufC, jb + 2 * B);
+        code(bufA, jb);
+        load(bufA, jb + 3 * B);
+        code(bufB, jb + B);
+        load(bufB, jb + 4 * B);
+        code(bufC, jb + 2 * B);
+    }
+    golf_finish<WRITE>(g, n > 0, recip);
+}
+
+// functor form (any per-lane row choice), used only where lanes of one wave disagree about the planes
+template <bool WRITE, class Fetch, class Need = NoWait>
+__device__ __forceinline__ void golf_stream_fn(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
                                             const uint32_t *recip, Fetch &&fetch, Need &&need = Need())
 {
     constexpr int B = 16;
