@@ -49,6 +49,15 @@ def cpu_baseline(fmt, pcm_host, packets, gpu_stream=None, gpu_sizes=None):
                        f"oracle/alac_oracle.c -O2 single thread, {dt:.2f} s"), exact
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json (falls back to its text if the file is not there)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "encode Msamples/s (bit-exact) 44.1kHz/16-bit stereo, 1/2/4/8 GPU"
+
+
 def cpu_all_cores(fmt, packets):
     """The same CPU port on every host core at once (tools/cpu_all_cores.py: one worker process per core, run as
     a child process so that nothing here forks after the GPU is initialised).  SURVEY.md §8d."""
@@ -197,7 +206,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "encode Msamples/s (bit-exact) 44.1kHz/16-bit stereo",
+            "metric": baseline_metric(),
             "value": round(value, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
