@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import alac_amd  # noqa: E402
-from alac_amd.reassemble import reassemble_shards  # noqa: E402
+from alac_amd.reassemble import Reassembler  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -106,35 +106,45 @@ def main():
     # synthetic input, generated on the host once and made resident in HBM before any timing
     pcm_host = alac_amd.synth_pcm(rank * B, B, fmt)
     d_pcm = torch.from_numpy(pcm_host).cuda()
-    bufs = [ctx.encode_buffers(fmt, B) for _ in range(2)]
-    comm_stream = torch.cuda.Stream() if use_dist else None
-    gather = None
+    # N > 1: the re-assembly of step i runs on a side stream under the encode of step i+1.  It is pipelined in two
+    # phases (alac_amd.reassemble.Reassembler) so that the host never waits for the GPU between two encodes: the
+    # shard lengths of step i are exchanged right after its encode, the shard bytes one host step later.  Three
+    # output buffer sets rotate because a shard must stay untouched until its all-gather has run.
+    reassemble = use_dist and not args.no_reassemble
+    nbuf = 3 if reassemble else 2
+    bufs = [ctx.encode_buffers(fmt, B) for _ in range(nbuf)]
+    comm_stream = torch.cuda.Stream() if reassemble else None
+    ra = Reassembler(dist.group.WORLD) if reassemble else None
+    state = {"pending": None, "gather": None}
+
+    def finish_pending():
+        if state["pending"] is None:
+            return
+        h, b = state["pending"]
+        with torch.cuda.stream(comm_stream):
+            state["gather"] = ra.finish(h)
+            done = torch.cuda.Event()
+            done.record()
+        b["done"] = done  # the buffer set may be encoded into again once this has run
+        state["pending"] = None
 
     def step(i):
-        nonlocal gather
-        b = bufs[i & 1]
+        b = bufs[i % nbuf]
+        if "done" in b:
+            torch.cuda.current_stream().wait_event(b.pop("done"))
         ctx.encode(fmt, d_pcm, B, bufs=b)
-        if use_dist and not args.no_reassemble:
-            # re-assembly of step i runs on the side stream under the encode of step i+1
+        if reassemble:
             ev = torch.cuda.Event()
             ev.record()
+            finish_pending()  # bytes of step i-1: runs under the encode of step i just launched
             comm_stream.wait_event(ev)
             with torch.cuda.stream(comm_stream):
-                gather = reassemble_shards(b["out"], b["offsets"][-1:], dist.group.WORLD, gather)
-            # the buffer pair is reused two steps later: make the main stream wait for this gather then
-            done = torch.cuda.Event()
-            done.record(comm_stream)
-            b["done"] = done
+                state["pending"] = (ra.begin(b["out"], b["offsets"][-1:]), b)
         return b
 
-    def wait_reuse(i):
-        b = bufs[i & 1]
-        if "done" in b:
-            torch.cuda.current_stream().wait_event(b["done"])
-
     for i in range(args.warmup):
-        wait_reuse(i)
         step(i)
+    finish_pending()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -143,8 +153,8 @@ def main():
     ctx.profile_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        wait_reuse(i)
-        last = step(i)
+        last = step(args.warmup + i)
+    finish_pending()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -263,7 +273,8 @@ def main():
             out["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
             out["cpu_all_cores"] = cpu_all_cores(fmt, n)
         print(json.dumps(out), flush=True)
-    if rank == 0 and use_dist and not args.no_reassemble and gather is not None:
+    gather = state["gather"]
+    if rank == 0 and reassemble and gather is not None:
         # the re-assembled stream on this rank must be the rank-ordered concatenation; rank 0's own shard leads it
         n0 = int(last["offsets"][-1].item())
         ok = bool(torch.equal(gather["stream"][:n0], last["out"][:n0])) and gather["total"] >= n0

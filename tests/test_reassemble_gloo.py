@@ -16,7 +16,7 @@ def _worker(rank, world, port, per_rank, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import alac_amd
-    from alac_amd.reassemble import reassemble_shards
+    from alac_amd.reassemble import Reassembler, reassemble_shards
     from oracle_lib import Oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,6 +30,14 @@ def _worker(rank, world, port, per_rank, q):
     res = None
     for _ in range(2):  # second call reuses the cached buffers
         res = reassemble_shards(shard, torch.tensor([len(s)], dtype=torch.int64), None, res)
+    # the pipelined two-phase form (what bench.py uses at N > 1) must give the same stream
+    ra = Reassembler()
+    h1 = ra.begin(shard, torch.tensor([len(s)], dtype=torch.int64))
+    h2 = ra.begin(shard, torch.tensor([len(s)], dtype=torch.int64))
+    r1 = ra.finish(h1)
+    first = r1["stream"][:r1["total"]].clone()
+    r2 = ra.finish(h2)
+    assert torch.equal(first, res["stream"][:res["total"]]) and torch.equal(r2["stream"][:r2["total"]], first)
     q.put((rank, res["stream"][:res["total"]].numpy().copy(), res["offsets"].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
