@@ -980,7 +980,8 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             const bool fuse = fused && H == 1;  // flag words are indexed by workgroup: one sub-batch only
             const uint32_t nLms = (nseg * CH + 31) / 32;
             if constexpr (CH == 2) {
-                if (fuse) {
+                // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
+                if (fuse && A.S.frameSize / 8 < 65536u) {
                     (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
                     hipLaunchKernelGGL(k_search1_fused<DEPTH>, dim3(nLms + 5 * cblocks), dim3(64), 0, sh, A, nLms, cblocks,
                                        chanBits);

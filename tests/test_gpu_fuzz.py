@@ -72,3 +72,21 @@ def test_random_layouts_match_oracle_and_round_trip(gpu_ctx, oracle, seed):
     for p in range(n):
         a, b = p * fmt.packet_bytes, p * fmt.packet_bytes + ns[p] * bpf
         assert np.array_equal(got[a:b], pcm[a:b]), (seed, p)
+
+
+@pytest.mark.parametrize("frame,depth,channels", [(16384, 16, 2), (65536, 24, 2), (8192, 16, 1)])
+def test_large_frames(gpu_ctx, oracle, frame, depth, channels):
+    """frame sizes well beyond the default 4096 (many tiles, long planes)"""
+    import torch
+    rng = np.random.default_rng(frame)
+    fmt = alac_amd.make_format(frame, depth, channels)
+    n = 3
+    pcm = np.concatenate([noisy_music(rng, frame, channels, depth) for _ in range(n)])
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n)
+    enc = oracle.encoder(frame, depth, channels)
+    ref, ref_sizes = enc.encode_stream(pcm, n * frame, segment_packets=1)
+    assert np.array_equal(sizes, ref_sizes) and np.array_equal(stream, ref)
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])).cuda()
+    out, dns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), torch.from_numpy(stream).cuda(), offs, n)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and np.array_equal(out.cpu().numpy(), pcm)
