@@ -51,29 +51,34 @@ __global__ __launch_bounds__(256) void k_dec_stage(const uint8_t *stream, const 
 }
 
 // ---- per-lane bit window ---------------------------------------------------------------------------
+// Two consecutive stream words in registers plus the bit offset into the first; the third word is always already
+// read from the LDS ring (its latency is covered by the symbols decoded before it is needed).  Skipping is
+// branch-free: the words move down under a select when the offset crosses 32.
 struct BitWin {
-    uint64_t win;        // next bits, left aligned
-    uint32_t have;       // valid bits in win (>= 32 between operations)
-    uint32_t idx;        // ring index of the look-ahead word
-    uint32_t nw;         // look-ahead word (already read from the ring)
-    uint32_t pos;        // bits consumed since the packet's first staged word
+    uint32_t w0, w1;     // words idx-2 and idx-1 of the lane's word stream
+    uint32_t o;          // bits of w0 already consumed (0..31)
+    uint32_t idx;        // index of the look-ahead word (relative to the packet's first staged word)
+    uint32_t nw;         // look-ahead word, ring[(idx - org) & 31]
     uint32_t org;        // word index that lives in ring slot 0
     const uint32_t *ring;
 };
 
-__device__ __forceinline__ uint32_t bw_peek(const BitWin &b) { return (uint32_t)(b.win >> 32); }
+__device__ __forceinline__ uint32_t bw_pos(const BitWin &b) { return (b.idx - 2u) * 32u + b.o; }
+
+__device__ __forceinline__ uint32_t bw_peek(const BitWin &b)
+{
+    return b.o ? ((b.w0 << b.o) | (b.w1 >> (32u - b.o))) : b.w0;
+}
 
 __device__ __forceinline__ void bw_skip(BitWin &b, uint32_t n)  // n <= 32
 {
-    b.win <<= n;
-    b.have -= n;
-    b.pos += n;
-    if (b.have < 32) {
-        b.win |= (uint64_t)b.nw << (32 - b.have);
-        b.have += 32;
-        b.idx++;
-        b.nw = b.ring[(b.idx - b.org) & 31u];
-    }
+    const uint32_t t = b.o + n;
+    const bool carry = t >= 32u;
+    b.o = t & 31u;
+    b.w0 = carry ? b.w1 : b.w0;
+    b.w1 = carry ? b.nw : b.w1;
+    b.idx += carry ? 1u : 0u;
+    b.nw = b.ring[(b.idx - b.org) & 31u];
 }
 
 __device__ __forceinline__ uint32_t bw_get(BitWin &b, uint32_t n)  // 1 <= n <= 32
@@ -260,21 +265,6 @@ __global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
     }
 }
 
-// branch-free skip: the refill is a select, the look-ahead word is re-read every time (its latency is covered
-// by the symbols decoded before the next refill needs it)
-__device__ __forceinline__ void bw_skip_bf(BitWin &b, uint32_t n)  // n <= 32
-{
-    b.win <<= n;
-    b.have -= n;
-    b.pos += n;
-    const bool refill = b.have < 32;
-    const uint64_t add = (uint64_t)b.nw << ((32 - b.have) & 31);
-    b.win |= refill ? add : 0ull;
-    b.have += refill ? 32u : 0u;
-    b.idx += refill ? 1u : 0u;
-    b.nw = b.ring[(b.idx - b.org) & 31u];
-}
-
 // per-lane state of the entropy kernel
 struct EntLane {
     BitWin bw;
@@ -320,7 +310,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
             E.F = pendBase + 16;
             pending = false;
         }
-        if (E.active && E.F - (bw.pos >> 5) <= 16) {
+        if (E.active && E.F - (bw.idx - 2u) <= 16) {
             fetch16(E.F, q);
             pending = true;
             pendBase = E.F;
@@ -328,7 +318,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < kDecRound; it++) {
-            if (E.active && E.F * 32 - bw.pos >= 160) {
+            if (E.active && E.F - bw.idx >= 4) {  // >= 160 staged bits ahead of the window
                 // ---- one residual: dyn_get_32bit (ag_dec.c:220-270), straight-line for the common case ----
                 const uint32_t k = min(22u - (uint32_t)__builtin_clz(E.mb + (3u << kQBShift)), A.kb);  // lg3a(mb >> 9)
                 const uint32_t m = (1u << k) - 1;
@@ -338,20 +328,17 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                 const uint32_t big = v >= 2 ? 1u : 0u;
                 uint32_t n = k != 1 ? pre * m + (big ? v - 1 : 0u) : pre;
                 uint32_t used = pre + 1 + (k != 1 ? k - 1 + big : 0u);
-                const bool lim = !(bw.pos < limit);  // ag_dec.c:302
-                const bool esc = pre >= kMaxPrefix;
-                if (__any(lim || esc)) {
-                    if (lim) {
-                        E.status = -50;
-                        E.active = 0;
-                        used = 0;
-                    } else if (esc) {
+                // (ag_dec.c:302 stops a channel whose next residual would start at or past the packet's end; such a
+                // channel also fails the end check below — the position only grows — so the status is the same and
+                // the per-residual test is not repeated here)
+                if (__any(pre >= kMaxPrefix)) {
+                    if (pre >= kMaxPrefix) {
                         bw_skip(bw, kMaxPrefix);
                         n = bw_get(bw, chanBits);
                         used = 0;
                     }
                 }
-                bw_skip_bf(bw, used);
+                bw_skip(bw, used);
                 const uint32_t nd = n + E.zmode;
                 // ((nd + 1) >> 1) * (nd odd ? -1 : 1); stored even when the packet just failed (c < numSamples still)
                 E.row[E.c] = (int32_t)((nd >> 1) ^ (0u - (nd & 1u)));
@@ -393,7 +380,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                     }
                     if (E.active && E.c >= numSamples) {
                         // channel complete: ag_dec.c:359 end check; the next channel starts where this one ended
-                        if ((uint64_t)(bw.pos - bit0 + 7) / 8 > nbytes) {
+                        if ((uint64_t)(bw_pos(bw) - bit0 + 7) / 8 > nbytes) {
                             E.status = -50;
                             E.active = 0;
                         } else if (E.chan + 1 < ech) {
@@ -457,13 +444,12 @@ __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
     asm volatile("" ::: "memory");
     E.F = cur0 + 16;
     {
-        const uint32_t sh = pos0 & 31;
         E.bw.ring = ringRow;
-        E.bw.win = (((uint64_t)ringRow[0] << 32) | ringRow[1]) << sh;
-        E.bw.have = 64 - sh;
+        E.bw.w0 = ringRow[0];
+        E.bw.w1 = ringRow[1];
+        E.bw.o = pos0 & 31;
         E.bw.idx = cur0 + 2;
         E.bw.nw = ringRow[2];
-        E.bw.pos = pos0;
         E.bw.org = cur0;
     }
     E.active = coded ? 1u : 0u;
