@@ -318,7 +318,8 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < kDecRound; it++) {
-            if (E.active && E.F - bw.idx >= 4) {  // >= 160 staged bits ahead of the window
+            // still decoding, and >= 160 staged bits ahead of the window (one condition, one branch)
+            if ((uint32_t)(E.active != 0) & (uint32_t)(E.F - bw.idx >= 4)) {
                 // ---- one residual: dyn_get_32bit (ag_dec.c:220-270), straight-line for the common case ----
                 const uint32_t k = min(22u - (uint32_t)__builtin_clz(E.mb + (3u << kQBShift)), A.kb);  // lg3a(mb >> 9)
                 const uint32_t m = (1u << k) - 1;
