@@ -114,15 +114,18 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
     g.nz += sw;
     const uint32_t capf = sw & ((g.nz + 1u) >> 16);                    // the run just reached 65535
     const uint32_t cl = inr & (nzf | capf);                            // the run ends before / at this residual
-    // (B)
-    if (__any(cl != 0)) {
+    // (B) a scalar test and branch over the (rare) close; no exec-mask change on the way that skips it
+    if (__builtin_amdgcn_ballot_w64(cl != 0) != 0) {
         if (cl) {
             golf_close_run<WRITE>(g, recip);
             if (capf) g.zmode = 0;
         }
     }
-    // (C) ag_enc.c:285-331
-    if (CHECKED ? (valid && !sw) : !sw) {
+    // (C) ag_enc.c:285-331.  Where every lane of the wave is inside its stream (!CHECKED) the symbol is computed
+    // by ALL lanes and a lane that swallowed a zero simply keeps its state and appends nothing: an exec-masked
+    // region costs a lone wave a save/branch/restore sequence worth a dozen instructions, the selects cost six.
+    const bool live = CHECKED ? (valid && !sw) : !sw;
+    if (CHECKED ? live : true) {
         // k = min(lg3a(mb >> 9), kb); lg3a(x) = 31 - clz(x + 3) and clz((mb >> 9) + 3) = clz(mb + 1536) + 9
         const uint32_t k = min(22u - (uint32_t)__builtin_clz(g.mb + (3u << kQBShift)), kKB0);
         const uint32_t m = (1u << k) - 1;
@@ -147,16 +150,20 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
             numBits = kMaxPrefix + bitSize;
             value = (((1u << kMaxPrefix) - 1) << bitSize) | (n & ((1u << bitSize) - 1));
         }
+        if (!live) {
+            numBits = 0;
+            value = 0;
+        }
         golf_put<WRITE>(g, value, numBits);
         // mb = pb * (n + zmode) + mb - ((pb * mb) >> 9), pb = 40   (:318)
         // (mb can pass 2^24 under sustained large residuals: shifts, not a 24-bit multiply; t2 < 2^24 always)
         uint32_t mb = __umul24(t2, 40u) + g.mb - (((g.mb << 5) + (g.mb << 3)) >> kQBShift);
         mb = n > kMeanClamp ? kMeanClamp : mb;
         const bool enter = mb < (1u << (kQBShift - 2));  // (mb << 2) < QB, :328
-        g.mb = mb;
-        g.zmode = enter ? 1u : 0u;
-        g.inrun = enter ? 1u : 0u;
-        g.nz = enter ? 0u : g.nz;
+        g.mb = live ? mb : g.mb;
+        g.zmode = live ? (enter ? 1u : 0u) : g.zmode;
+        g.inrun = live ? (enter ? 1u : 0u) : g.inrun;
+        g.nz = (live && enter) ? 0u : g.nz;
     }
 }
 
