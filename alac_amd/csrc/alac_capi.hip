@@ -76,7 +76,8 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.recs = off;
     off = align_up(off + (uint64_t)numPackets * sizeof(PacketRec), 256);
     L.bitWords = off;
-    off = align_up(off + (uint64_t)numPackets * 2 * L.wcap * 4, 256);
+    // + one spare packet slot: lanes that own no packet write their (ignored) bit words there
+    off = align_up(off + ((uint64_t)numPackets + 1) * 2 * L.wcap * 4, 256);
     L.pred = off;
     off = align_up(off + (uint64_t)(f->frame_size / 8 + 1) * lanes * 4, 256);
     L.chainsPad = (uint32_t)lanes;

@@ -127,6 +127,7 @@ struct V1Args {
     uint32_t chainsPad;    // numSegments * channels rounded up to 64
     uint32_t *bitWords;
     uint32_t wcap;
+    uint32_t dumpSlot;     // channel slot index (2 * numPackets) no packet owns: bit words of lanes without a packet
     uint32_t *packetBytes;
     uint32_t *flags;       // producer progress words of the fused final kernel (zeroed per call)
     uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
@@ -451,6 +452,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
     const int slot = lane / LPC;
     LmsLane L = make_lane<LPC>(lane, J.na, J.active ? (int)num : 0);
+    // Lanes without work (pad lanes, escape packets in the final pass) must not drag the wave onto the checked
+    // paths: they count as "live", as owning every row and as fully inside their packet.  What they compute and
+    // store goes to rows / slots nobody reads.
+    if (!J.active) {
+        L.jlo = 0;
+        L.jhi = 0x7fffffff;
+    }
     LaneView V;
     V.feeds = J.active && (4 * L.h < J.na);
     V.row = sh.xs + slot * kXsStride;
@@ -465,12 +473,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     // flush: the lane's column inside a group of LPC rows, and the first row some lane does NOT own
     const uint32_t half = (uint32_t)(lane / SLOTS);
     const uint32_t voff = half * (uint32_t)streamStride + fStream;
-    const uint32_t fPmin = wave_min_u32(fP);
+    const bool fAct = __shfl((int)J.active, fs * LPC) != 0;
+    const uint32_t fPmin = wave_min_u32(fAct ? fP : 0xffffffffu);
     StageRegs<CH, LPC> R;
     StagePlan<CH, LPC> SP;
     stage_plan<DEPTH, CH, LPC>(SP, sh, A.S.pcm, frameBytes, lane);
     // staged window [j - kHist, j - kHist + kRowLen) inside every packet of the wave -> fast staging of tile j
-    const uint32_t nMinRows = wave_min_u32(J.active ? J.N : 0);
+    const uint32_t nMinRows = wave_min_u32(J.active ? J.N : 0xffffffffu);
     auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + kRowLen) <= nMinRows; };
     if (runTo > 0) {
         stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
@@ -830,6 +839,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x;
     uint32_t p, N;
     bool active = seg_packet(A.S, chain / CH, p, N);
+    const bool have = active;  // the lane's packet exists (its bit-word slot may be scribbled on even if it escapes)
     PacketRec *rec = A.recs + p;
     if (active && rec->escape) active = false;
     const uint32_t c = chain % CH;
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     const uint64_t stride = A.chainsPad;
     GolF g;
     golf_reset(g);
-    g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
+    g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
     g.wleft = A.wcap - 1;
     golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain));
     golf_flush<true>(g);
@@ -886,6 +896,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         const uint32_t chain = A.S.segBegin * CH + w * 64u + lane;
         uint32_t p, N;
         bool active = seg_packet(A.S, chain / CH, p, N);
+        const bool have = active;
         PacketRec *rec = A.recs + p;
         if (active && rec->escape) active = false;
         const uint32_t c = chain % CH;
@@ -894,7 +905,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         const uint64_t stride = A.chainsPad;
         GolF g;
         golf_reset(g);
-        g.wp = A.bitWords + ((uint64_t)p * 2 + c) * A.wcap;
+        g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
         g.wleft = A.wcap - 1;
         RowWait wait;
         wait.f0 = A.flags + 2 * w;
@@ -1058,6 +1069,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.chainsPad = vb.chainsPad;
     A.bitWords = ea.bitWords;
     A.wcap = ea.wcap;
+    A.dumpSlot = numPackets * 2;
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;
     {

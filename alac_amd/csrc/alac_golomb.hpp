@@ -244,10 +244,12 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
             }
         }
     };
-    const uint32_t nMinWave = wave_min_u32(n);
+    // lanes without a stream (n = 0: pad lanes, escape packets) do not count: in the unchecked blocks they code
+    // whatever they load into state and bit words nobody reads (their wp points at a spare slot)
+    const uint32_t nMinWave = wave_min_u32(n ? n : 0xffffffffu);
     auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
         if (jb >= nMaxWave) return;
-        if (jb + B <= nMinWave) {  // every lane owns the whole block
+        if (jb + B <= nMinWave) {  // every lane that has a stream owns the whole block
 #pragma unroll
             for (int s = 0; s < B; s++) golf_sym<WRITE, false>(g, buf[s], true, bitSize, recip);
         } else {
@@ -282,10 +284,12 @@ __device__ __forceinline__ void golf_stream_fn(GolF &g, uint32_t n, uint32_t nMa
             for (int s = 0; s < B; s++) buf[s] = fetch(jb + s);
         }
     };
-    const uint32_t nMinWave = wave_min_u32(n);
+    // lanes without a stream (n = 0: pad lanes, escape packets) do not count: in the unchecked blocks they code
+    // whatever they load into state and bit words nobody reads (their wp points at a spare slot)
+    const uint32_t nMinWave = wave_min_u32(n ? n : 0xffffffffu);
     auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
         if (jb >= nMaxWave) return;
-        if (jb + B <= nMinWave) {  // every lane owns the whole block
+        if (jb + B <= nMinWave) {  // every lane that has a stream owns the whole block
 #pragma unroll
             for (int s = 0; s < B; s++) golf_sym<WRITE, false>(g, buf[s], true, bitSize, recip);
         } else {
