@@ -298,7 +298,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
 #pragma unroll
         for (int i = 0; i < 16; i++) dst[i] = q[i];
     };
-    auto mul_pb = [&](uint32_t x) { return PB40 ? (x << 5) + (x << 3) : E.pb * x; };
+    auto mul_pb = [&](uint32_t x) { return PB40 ? times5(x) << 3 : E.pb * x; };  // wraps like the reference's uint32
 
     uint32_t q[16];
     bool pending = false;

@@ -37,6 +37,14 @@ __device__ __forceinline__ int32_t sext(int32_t x, uint32_t chanshift)
     return (int32_t)((uint32_t)x << chanshift) >> chanshift;
 }
 __device__ __forceinline__ int32_t sign_of(int32_t x) { return min(max(x, -1), 1); }
+// x * 5 as one shift-add (the compiler turns (x << 2) + x back into a quarter-rate 32-bit multiply)
+__device__ __forceinline__ uint32_t times5(uint32_t x)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // lead(): codec/ag_enc.c:65-77, lead(0) == 32
 __device__ __forceinline__ int32_t lead(uint32_t m) { return m ? __clz((int)m) : 32; }
 __device__ __forceinline__ int32_t lg3a(uint32_t x) { return 31 - lead(x + 3); }

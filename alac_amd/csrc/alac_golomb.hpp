@@ -157,7 +157,8 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
         golf_put<WRITE>(g, value, numBits);
         // mb = pb * (n + zmode) + mb - ((pb * mb) >> 9), pb = 40   (:318)
         // (mb can pass 2^24 under sustained large residuals: shifts, not a 24-bit multiply; t2 < 2^24 always)
-        uint32_t mb = __umul24(t2, 40u) + g.mb - (((g.mb << 5) + (g.mb << 3)) >> kQBShift);
+        // (40 mb) >> 9 == (5 mb) >> 6, and 5 mb < 2^32 for every reachable mb (< 2^26)
+        uint32_t mb = __umul24(t2, 40u) + g.mb - (times5(g.mb) >> (kQBShift - 3));
         mb = n > kMeanClamp ? kMeanClamp : mb;
         const bool enter = mb < (1u << (kQBShift - 2));  // (mb << 2) < QB, :328
         g.mb = live ? mb : g.mb;
