@@ -131,6 +131,7 @@ struct V1Args {
     uint32_t *packetBytes;
     uint32_t *flags;       // producer progress words of the fused final kernel (zeroed per call)
     uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
+    uint32_t idleFast;     // 1: lanes without work do not force the checked paths (latency regime, see launcher)
 };
 
 // ================================================================================================
@@ -455,7 +456,8 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     // Lanes without work (pad lanes, escape packets in the final pass) must not drag the wave onto the checked
     // paths: they count as "live", as owning every row and as fully inside their packet.  What they compute and
     // store goes to rows / slots nobody reads.
-    if (!J.active) {
+    const uint32_t idleVal = A.idleFast ? 0xffffffffu : 0u;  // what a lane without work reports to the wave minima
+    if (!J.active && A.idleFast) {
         L.jlo = 0;
         L.jhi = 0x7fffffff;
     }
@@ -474,12 +476,12 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     const uint32_t half = (uint32_t)(lane / SLOTS);
     const uint32_t voff = half * (uint32_t)streamStride + fStream;
     const bool fAct = __shfl((int)J.active, fs * LPC) != 0;
-    const uint32_t fPmin = wave_min_u32(fAct ? fP : 0xffffffffu);
+    const uint32_t fPmin = wave_min_u32(fAct ? fP : idleVal);
     StageRegs<CH, LPC> R;
     StagePlan<CH, LPC> SP;
     stage_plan<DEPTH, CH, LPC>(SP, sh, A.S.pcm, frameBytes, lane);
     // staged window [j - kHist, j - kHist + kRowLen) inside every packet of the wave -> fast staging of tile j
-    const uint32_t nMinRows = wave_min_u32(J.active ? J.N : 0xffffffffu);
+    const uint32_t nMinRows = wave_min_u32(J.active ? J.N : idleVal);
     auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + kRowLen) <= nMinRows; };
     if (runTo > 0) {
         stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     golf_reset(g);
     g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
     g.wleft = A.wcap - 1;
-    golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain));
+    golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), NoWait(), A.idleFast != 0);
     golf_flush<true>(g);
     if (active) rec->c[c].bits = g.bits;
 }
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = 0;
-        golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait);
+        golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
         golf_flush<true>(g);
         if (active) rec->c[c].bits = g.bits;
     }
@@ -1070,6 +1072,14 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.bitWords = ea.bitWords;
     A.wcap = ea.wcap;
     A.dumpSlot = numPackets * 2;
+    {
+        // Latency regime (about one wave per SIMD: up to ~2 x 1024 x 32 chains): idle lanes should not slow their
+        // wave down.  With many waves per SIMD the machine is throughput bound and the extra work of idle lanes
+        // costs more than the checked paths (measured: 125 000 packets 18.6 ms vs 20.3 ms).  ALAC_HIP_IDLEFAST=0/1 forces.
+        static const int forced = [] { const char *v = getenv("ALAC_HIP_IDLEFAST"); return v ? atoi(v) : -1; }();
+        const uint64_t chains = (uint64_t)ea.numSegments * channels;
+        A.idleFast = forced >= 0 ? (uint32_t)forced : (chains <= 65536 ? 1u : 0u);
+    }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;
     {
