@@ -126,7 +126,7 @@ bool use_lane_encoder()
 }
 
 struct DecLayout {
-    uint64_t recs, resid, words, capWords, total;
+    uint64_t recs, resid, words, capWords, prog, total;
 };
 
 DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
@@ -141,6 +141,8 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
     L.words = off;
     L.capWords = ((uint64_t)numPackets * alac_hip_encode_max_output_bytes(f, 1) + 3) / 4 + 64;
     off = align_up(off + L.capWords * 4, 256);
+    L.prog = off;
+    off = align_up(off + (uint64_t)numPackets * 8, 256);
     L.total = off;
     return L;
 }
@@ -501,7 +503,7 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.statusOut = d_status;
     hipError_t e = use_lane_decoder()
                        ? launch_decode(da, ctx->stream)
-                       : launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, ctx->stream);
+                       : launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "decode launch", e);
     return ALAC_HIP_noErr;
 }

@@ -95,11 +95,20 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+__device__ __forceinline__ uint32_t wave_min_dec(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 struct DecV1Args {
     DecodeArgs d;
     const uint32_t *words;   // staged stream
     uint64_t capWords;
     int32_t *plane;          // [packet][channel][frameSize]
+    uint32_t *prog;          // fused launch: [packet][2] residuals completed per channel (0xffffffff = all)
+    uint32_t pubMask;        // the entropy lanes publish every (pubMask + 1) rounds of 16 symbols
 };
 
 // lane states of the entropy kernel
@@ -277,10 +286,13 @@ struct EntLane {
 
 // The rounds of one wave.  PB40: every lane uses pb = 40 (pbFactor 4 with the standard cookie — every stream this
 // library or Apple's encoder writes), so pb * x is two shifts; otherwise full 32-bit multiplies.
-template <bool PB40>
+// PUB: fused launch — the lane publishes how many residuals are complete every (pubMask + 1) rounds (drain,
+// agent-scope release, one flag store per channel) for the predictor waves that follow it.
+template <bool PB40, bool PUB>
 __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, uint32_t *ringRow, uint64_t wordBase,
                                                uint32_t cur0, uint32_t bit0, uint32_t limit, uint64_t nbytes,
-                                               uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV)
+                                               uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV,
+                                               uint32_t *prog)
 {
     const DecodeArgs &A = V.d;
     const uint32_t wb = (1u << A.kb) - 1;
@@ -303,7 +315,24 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
     uint32_t q[16];
     bool pending = false;
     uint32_t pendBase = 0;
+    uint32_t round = 0;
     BitWin &bw = E.bw;
+    auto publish = [&]() {
+        if constexpr (PUB) {
+            // per-lane 4-byte stores cannot be written through one by one (16 x HBM write amplification, measured):
+            // plain stores, and an agent-scope release (L2 write-back, ~10 us) at every publish instead
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t all = 0xffffffffu;
+            const uint32_t u = (!E.active || E.chan > 0) ? all : E.c;
+            const uint32_t v = !E.active ? all : (E.chan > 0 ? E.c : 0u);
+            if (prog) {
+                __hip_atomic_store(prog, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(prog + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     while (__any(E.active != 0)) {
         if (pending) {
             write16(pendBase, q);
@@ -399,15 +428,17 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
             }
         }
         asm volatile("" ::: "memory");
+        if (PUB && (++round & V.pubMask) == 0) publish();
     }
+    publish();  // everything is complete (or failed): nobody waits for this lane any more
 }
 
-__global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
+template <bool PUB>
+__device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block)
 {
-    __shared__ uint32_t ring[64 * kWinStride];
     const DecodeArgs &A = V.d;
     const int lane = threadIdx.x;
-    const uint32_t p = blockIdx.x * 64u + lane;
+    const uint32_t p = block * 64u + lane;
     const bool live = p < A.numPackets;
     const uint64_t off = live ? A.offsets[p] : 0;
     const uint64_t nbytes = live ? A.offsets[p + 1] - off : 0;
@@ -462,16 +493,23 @@ __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
     E.status = status0;
     E.row = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
 
+    uint32_t *prog = (PUB && live) ? V.prog + (uint64_t)p * 2 : nullptr;
     if (__all(!coded || (pbU == 40 && pbV == 40)))
-        entropy_rounds<true>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV);
+        entropy_rounds<true, PUB>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
     else
-        entropy_rounds<false>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV);
+        entropy_rounds<false, PUB>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
 
     if (live && E.status != status0) {
         rec->status = E.status;
         A.statusOut[p] = E.status;
         A.numSamplesOut[p] = 0;
     }
+}
+
+__global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
+{
+    __shared__ uint32_t ring[64 * kWinStride];
+    entropy_body<false>(V, ring, blockIdx.x);
 }
 
 // ---- unpc_block (codec/dp_dec.c:55-381), in place over the chain's row ----
@@ -515,17 +553,47 @@ __device__ __forceinline__ void unpc_head16(const int32_t (&del)[16], int32_t (&
     for (int k = 0; k < NA; k++) a8[k] = s.a[k];
 }
 
-__global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V)
+// FOLLOW: fused launch — the wave's chains are all of one channel (q = channel * numPackets + packet), and rows are
+// only read once the entropy lane of their packet has published them.
+template <bool FOLLOW>
+__device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t block)
 {
     const DecodeArgs &A = V.d;
     const int lane = threadIdx.x;
-    const uint64_t chain = (uint64_t)blockIdx.x * 32u + lane / 2;
-    const bool inRange = chain < (uint64_t)A.numPackets * A.numChannels;
-    const uint32_t p = inRange ? (uint32_t)(chain / A.numChannels) : 0, ch = inRange ? (uint32_t)(chain % A.numChannels) : 0;
+    const uint64_t q = (uint64_t)block * 32u + lane / 2;
+    const bool inRange = q < (uint64_t)A.numPackets * A.numChannels;
+    uint32_t p, ch;
+    if (FOLLOW) {
+        ch = inRange ? (uint32_t)(q / A.numPackets) : 0;
+        p = inRange ? (uint32_t)(q % A.numPackets) : 0;
+    } else {
+        p = inRange ? (uint32_t)(q / A.numChannels) : 0;
+        ch = inRange ? (uint32_t)(q % A.numChannels) : 0;
+    }
+    const uint64_t chain = (uint64_t)p * A.numChannels + ch;
     const DecRec *rec = A.recs + p;
     const bool active = inRange && unpc_fast_ok(A, rec, ch);
     if (!__any(active)) return;
     const uint32_t n = active ? rec->numSamples : 0;
+    // rows < `rows` (capped at the lane's own length) must have been published before they are loaded
+    const uint32_t *progPtr = V.prog + (uint64_t)p * 2 + ch;
+    uint32_t availMin = 0;
+    auto need = [&](uint32_t rows) {
+        if constexpr (FOLLOW) {
+            if (availMin >= rows) return;
+            const uint32_t want = active ? min(rows, n) : 0u;
+            for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+                const uint32_t a = active ? __hip_atomic_load(progPtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                if (__all(a >= want)) {
+                    availMin = wave_min_dec(a);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    };
+    need(16);
     const int na = active ? (int)rec->c[ch].num : 4;
     const uint32_t chanbits = A.bitDepth - (active ? rec->bytesShifted : 0) * 8 + ((active ? rec->elementChannels : 1) == 2 ? 1 : 0);
     int32_t *row = V.plane + (inRange ? chain : 0) * A.frameSize;
@@ -567,8 +635,10 @@ __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V)
         d[4] = t1.x; d[5] = t1.y; d[6] = t1.z; d[7] = t1.w;
     };
     int32_t dA[8], dB[8];
+    need(min(24u, nMax));
     load8(16, dA);
-    auto block = [&](uint32_t jb, const int32_t (&cur)[8], int32_t (&nxt)[8]) {
+    auto step8 = [&](uint32_t jb, const int32_t (&cur)[8], int32_t (&nxt)[8]) {
+        need(min(jb + 16, nMax));
         load8(jb + 8, nxt);
         int32_t o[8];
 #pragma unroll
@@ -579,9 +649,19 @@ __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V)
         }
     };
     for (uint32_t jb = 16; jb < nMax; jb += 16) {
-        block(jb, dA, dB);
-        if (jb + 8 < nMax) block(jb + 8, dB, dA);
+        step8(jb, dA, dB);
+        if (jb + 8 < nMax) step8(jb + 8, dB, dA);
     }
+}
+
+__global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_body<false>(V, blockIdx.x); }
+
+// ---- fused launch: entropy waves first (they are resident before any follower can wait), predictor waves behind
+__global__ __launch_bounds__(64) void k_dec_fused(DecV1Args V, uint32_t nEnt)
+{
+    __shared__ uint32_t ring[64 * kWinStride];
+    if (blockIdx.x < nEnt) entropy_body<true>(V, ring, blockIdx.x);
+    else unpc_fast_body<true>(V, blockIdx.x - nEnt);
 }
 
 __global__ __launch_bounds__(64) void k_dec_unpc(DecV1Args V)
@@ -672,7 +752,8 @@ static void launch_unmix_v1(const DecV1Args &V, hipStream_t st)
         hipLaunchKernelGGL((k_dec_unmix<DEPTH, 1>), grid, dim3(256), 0, st, V);
 }
 
-hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, hipStream_t st)
+hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
+                            hipStream_t st)
 {
     if (da.numPackets == 0) return hipSuccess;
     DecV1Args V;
@@ -680,14 +761,26 @@ hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capW
     V.words = words;
     V.capWords = capWords;
     V.plane = plane;
+    V.prog = prog;
+    {
+        static const uint32_t pm = [] { const char *v = getenv("ALAC_HIP_DEC_PUBMASK"); return v ? (uint32_t)atoi(v) : 31u; }();
+        V.pubMask = pm;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
+    }
     const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
     (void)hipMemsetAsync(plane, 0, planeBytes, st);  // zero runs only move the index (k_dec_entropy)
     hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
     hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
     hipLaunchKernelGGL(k_dec_raw, dim3((da.frameSize + 1023) / 1024, da.numPackets), dim3(256), 0, st, V);
-    hipLaunchKernelGGL(k_dec_entropy, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
     const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
-    hipLaunchKernelGGL(k_dec_unpc_fast, dim3((uint32_t)((lanes + 31) / 32)), dim3(64), 0, st, V);
+    const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
+    static const bool fused = [] { const char *v = getenv("ALAC_HIP_DEC_FUSED"); return !(v && v[0] == '0'); }();
+    if (fused) {
+        (void)hipMemsetAsync(prog, 0, (size_t)da.numPackets * 8, st);
+        hipLaunchKernelGGL(k_dec_fused, dim3(nEnt + nUnpc), dim3(64), 0, st, V, nEnt);
+    } else {
+        hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
+        hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
+    }
     hipLaunchKernelGGL(k_dec_unpc, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
     switch (da.bitDepth) {
     case 16: launch_unmix_v1<16>(V, st); break;

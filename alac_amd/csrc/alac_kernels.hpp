@@ -127,8 +127,9 @@ struct DecodeArgs {
 
 hipError_t launch_decode(const DecodeArgs &da, hipStream_t st);
 // second generation (alac_decode_v1.hip): `words` = capWords uint32 of scratch for the re-staged stream, `plane` =
-// numPackets * numChannels * frameSize int32
-hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, hipStream_t st);
+// numPackets * numChannels * frameSize int32, `prog` = 2 * numPackets uint32 (progress words of the fused launch)
+hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
+                            hipStream_t st);
 
 // ---- stage-level ----
 hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
