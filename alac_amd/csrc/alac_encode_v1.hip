@@ -443,7 +443,8 @@ struct ChainJob {
 
 // A pass = one pc_block call over every chain of the wave: `num` samples adapt the row, residual positions
 // j < P go to dst[j * streamStride + stream] when store is set.
-template <int DEPTH, int CH, int LPC, bool WT = false>
+// ZZ: residuals leave as their zig-zag image 2|del| - (del < 0) (what the final entropy coder starts from)
+template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false>
 __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[4],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
                                          uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0)
@@ -508,6 +509,7 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
             // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams.  WT (fused launches):
             // agent-scope stores, written through so that publish_rows has nothing to write back.
             auto put = [&](int32_t *q, int32_t v) {
+                if constexpr (ZZ) v = (int32_t)(((uint32_t)v << 1) ^ (uint32_t)(v >> 31));
                 if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *q = v;
             };
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(64) void k_lms_final(V1Args A)
     int32_t a[4];
     load_row<2>(J, a, lane);
     lms_setup<2>(sh, J, best, lane);
-    lms_pass<DEPTH, CH, 2>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane);
+    lms_pass<DEPTH, CH, 2, false, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane);
     store_row<2>(J, a, lane);
 }
 
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     golf_reset(g);
     g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
     g.wleft = A.wcap - 1;
-    golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), NoWait(), A.idleFast != 0);
+    golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), NoWait(), A.idleFast != 0);
     golf_flush<true>(g);
     if (active) rec->c[c].bits = g.bits;
 }
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         load_row<2>(J, a, lane);
         lms_setup<2>(sh, J, best, lane);
         uint32_t *flag = A.flags + blockIdx.x;
-        lms_pass<DEPTH, CH, 2, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
+        lms_pass<DEPTH, CH, 2, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
         store_row<2>(J, a, lane);
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);  // nothing more will come (also covers inactive waves)
     } else {
@@ -914,7 +916,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = 0;
-        golf_stream<true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
+        golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
         golf_flush<true>(g);
         if (active) rec->c[c].bits = g.bits;
     }

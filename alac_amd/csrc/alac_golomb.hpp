@@ -102,12 +102,14 @@ __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
 // (zero run / normal / escape) does not execute long divergent bodies: (A) run bookkeeping, (B) run close,
 // entered only when some lane closes a run, (C) the symbol itself, straight-line (escape handled by selects).
 // Requires bitSize <= 23 so that the escape (9 ones + bitSize raw bits) is one <= 32-bit put.
-template <bool WRITE, bool CHECKED>
+// ZZ: the plane already holds the zig-zag image of the residuals (the final predictor pass stores it that way:
+// the map is three instructions per residual here, three per 64 residuals in the predictor's row flush)
+template <bool WRITE, bool CHECKED, bool ZZ = false>
 __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint32_t bitSize, const uint32_t *recip)
 {
     // (A) ag_enc.c:333-349, on 0/1 flags in vector registers (boolean chains through scalar masks cost a lone
     // wave three times as many instructions): del == 0 <=> its zig-zag image is 0
-    const uint32_t t2 = ((uint32_t)del << 1) ^ (uint32_t)(del >> 31);  // n + zmode = 2|del| - (del < 0)
+    const uint32_t t2 = ZZ ? (uint32_t)del : (((uint32_t)del << 1) ^ (uint32_t)(del >> 31));  // n + zmode = 2|del| - (del < 0)
     const uint32_t nzf = min(t2, 1u);                                  // del != 0
     const uint32_t inr = CHECKED ? (valid ? g.inrun : 0u) : g.inrun;
     const uint32_t sw = inr & (nzf ^ 1u);                              // a zero swallowed by the open run
@@ -218,7 +220,7 @@ __device__ __forceinline__ RowSrc one_plane(const int32_t *plane, uint64_t strid
     return r;
 }
 
-template <bool WRITE, class Need = NoWait>
+template <bool WRITE, bool ZZ = false, class Need = NoWait>
 __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
                                             const uint32_t *recip, const RowSrc &R, Need &&need = Need(),
                                             bool idleFast = true)
@@ -253,10 +255,10 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
         if (jb >= nMaxWave) return;
         if (jb + B <= nMinWave) {  // every lane that has a stream owns the whole block
 #pragma unroll
-            for (int s = 0; s < B; s++) golf_sym<WRITE, false>(g, buf[s], true, bitSize, recip);
+            for (int s = 0; s < B; s++) golf_sym<WRITE, false, ZZ>(g, buf[s], true, bitSize, recip);
         } else {
 #pragma unroll
-            for (int s = 0; s < B; s++) golf_sym<WRITE, true>(g, buf[s], jb + s < n, bitSize, recip);
+            for (int s = 0; s < B; s++) golf_sym<WRITE, true, ZZ>(g, buf[s], jb + s < n, bitSize, recip);
         }
     };
     load(bufA, 0);
