@@ -61,7 +61,10 @@ __device__ __forceinline__ bool seg_packet(const SegView &S, uint32_t seg, uint3
     const uint32_t p0 = S.segFirst ? S.segFirst[seg] : seg;
     const uint32_t p1 = S.segFirst ? S.segFirst[seg + 1] : seg + 1;
     p = p0 + S.pos;
-    if (p >= p1) return false;
+    if (p >= p1) {
+        p = 0;  // a lane without a packet still forms addresses from p (idle-lane fast paths): keep it in range
+        return false;
+    }
     N = S.numSamples ? S.numSamples[p] : S.frameSize;
     N = N < S.frameSize ? N : S.frameSize;
     return true;
