@@ -90,3 +90,36 @@ def test_large_frames(gpu_ctx, oracle, frame, depth, channels):
     out, dns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), torch.from_numpy(stream).cuda(), offs, n)
     gpu_ctx.synchronize()
     assert int(st.abs().sum()) == 0 and np.array_equal(out.cpu().numpy(), pcm)
+
+
+@pytest.mark.parametrize("depth,channels", [(16, 2), (24, 2), (16, 1)])
+def test_many_uneven_segments(gpu_ctx, oracle, depth, channels):
+    """several waves of chained segments of unequal length: at the later packet positions most lanes are idle,
+    at the first every lane works (the idle-lane paths of the predictor and coder kernels)"""
+    import torch
+    rng = np.random.default_rng(77 + depth + channels)
+    frame = 1024
+    fmt = alac_amd.make_format(frame, depth, channels)
+    nseg = 150
+    seg_len = rng.integers(1, 6, nseg)
+    seg_first = np.concatenate([[0], np.cumsum(seg_len)]).astype(np.int32)
+    n = int(seg_first[-1])
+    ns = np.full(n, frame, np.int32)
+    for s in range(nseg):
+        if rng.random() < 0.3:
+            ns[seg_first[s + 1] - 1] = int(rng.integers(1, frame + 1))
+    bpf = fmt.bytes_per_frame
+    pcm = np.zeros(n * fmt.packet_bytes, np.uint8)
+    for p in range(n):
+        pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * bpf] = noisy_music(rng, int(ns[p]), channels, depth)
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, num_samples=torch.from_numpy(ns).cuda(),
+                                           seg_first=torch.from_numpy(seg_first).cuda())
+    enc = oracle.encoder(frame, depth, channels)
+    off = 0
+    for s in range(nseg):
+        enc.reset()
+        for p in range(seg_first[s], seg_first[s + 1]):
+            pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * bpf], int(ns[p]))
+            assert sizes[p] == len(pk) and np.array_equal(stream[off:off + len(pk)], pk), (s, p)
+            off += len(pk)
+    assert off == len(stream)
