@@ -312,6 +312,7 @@ struct StagePlan {
     const uint8_t *pk[ITERS];  // address of the task's 4 sample-frames when the tile starts at j0 = kHist
     int xs[ITERS];             // LDS cell of the task's first u (v follows one row further)
     int32_t wl[ITERS], wr[ITERS], vsel[ITERS];  // u = (wl l + wr r) >> 2; v = vsel ? l - r : r
+    int32_t keep[ITERS];       // 0 for the tasks in front of sample 0 when the first tile is staged (HEAD), else -1
     bool usable;               // dword-aligned packets
 };
 
@@ -333,16 +334,26 @@ __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShare
         P.wl[it] = r ? r : (1 << kMixBits);
         P.wr[it] = r ? (1 << kMixBits) - r : 0;
         P.vsel[it] = r ? -1 : 0;
+        P.keep[it] = grp < kHist / 4 ? 0 : -1;
     }
 }
 
-template <int DEPTH, int CH, int LPC>
+// HEAD: the tile that starts at sample 0 — the kHist samples in front of it are zeros, their tasks load nothing
+template <int DEPTH, int CH, int LPC, bool HEAD = false>
 __device__ __forceinline__ void stage_load_fast(StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P, int j0)
 {
     constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
     const int64_t byteOff = (int64_t)(j0 - kHist) * BPF;
 #pragma unroll
-    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int k = 0; k <= BPF; k++) R.v[it][k] = 0;
+            if (P.keep[it]) task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
+        } else {
+            task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
+        }
+    }
 }
 
 template <int DEPTH, int CH, int LPC>
@@ -488,8 +499,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     const uint32_t nMinRows = wave_min_u32(J.active ? J.N : idleVal);
     auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + kRowLen) <= nMinRows; };
     if (runTo > 0) {
-        stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
-        stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+        if (SP.usable && (uint32_t)(kRowLen - kHist) <= nMinRows) {  // first tile inside every packet: no bounds checks
+            stage_load_fast<DEPTH, CH, LPC, true>(R, SP, 0);
+            stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
+        } else {
+            stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+            stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+        }
     }
     for (int j0 = 0; j0 < (int)runTo; j0 += kTile) {
         const bool more = j0 + kTile < (int)runTo;
