@@ -461,8 +461,12 @@ struct ChainJob {
 template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false>
 __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[4],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
-                                         uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0)
+                                         uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0,
+                                         StageRegs<CH, LPC> *head = nullptr, int headMode = 0)
 {
+    // head / headMode: the raw PCM of the first tile is the same for every pass a kernel makes over a packet
+    // (only the mix weights change): mode 1 keeps it in *head, mode 2 re-mixes it from there instead of loading
+    // it again — the first tile's load is the one load of a pass whose latency nothing hides.
     constexpr int SLOTS = 64 / LPC;
     constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
     const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
@@ -500,8 +504,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + kRowLen) <= nMinRows; };
     if (runTo > 0) {
         if (SP.usable && (uint32_t)(kRowLen - kHist) <= nMinRows) {  // first tile inside every packet: no bounds checks
-            stage_load_fast<DEPTH, CH, LPC, true>(R, SP, 0);
-            stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
+            if (head && headMode == 2) {
+                stage_store_fast<DEPTH, CH, LPC>(*head, SP, sh);
+            } else {
+                stage_load_fast<DEPTH, CH, LPC, true>(R, SP, 0);
+                if (head && headMode == 1) *head = R;
+                stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
+            }
         } else {
             stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
             stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
@@ -604,9 +613,11 @@ __global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
     int32_t a[4];
     load_row<2>(J, a, lane);
     const uint32_t n8 = J.N / 8;
+    StageRegs<2, 2> head;
     for (int r = 0; r <= kMaxRes; r++) {
         lms_setup<2>(sh, J, r, lane);
-        lms_pass<DEPTH, 2, 2>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane);
+        lms_pass<DEPTH, 2, 2>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
+                              nullptr, 0, &head, r == 0 ? 1 : 2);
     }
     store_row<2>(J, a, lane);
 }
@@ -630,13 +641,14 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
     const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
     lms_setup<LPC>(sh, J, best, lane);
     const uint32_t n8 = J.N / 8, n32 = J.N / 32;
+    StageRegs<CH, LPC> head;
     for (int pass = 0; pass < 8; pass++) {
         const bool last = pass == 7;
         const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
         uint32_t P = num > (uint32_t)(J.na + 1) ? num : (uint32_t)(J.na + 1);  // positions pc_block writes ...
         P = P < n8 ? P : n8;                                                   // ... that dyn_comp will read
         lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
-                                 lane);
+                                 lane, nullptr, 0, &head, pass == 0 ? 1 : 2);
     }
     store_row<LPC>(J, a, lane);
 }
@@ -728,10 +740,11 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         load_row<2>(J, a, lane);
         const uint32_t n8 = J.N / 8;
         uint32_t *flag = A.flags + blockIdx.x;
+        StageRegs<2, 2> head;
         for (int r = 0; r <= kMaxRes; r++) {
             lms_setup<2>(sh, J, r, lane);
             lms_pass<DEPTH, 2, 2, true>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain,
-                                        lane, flag, (uint32_t)r << 16);
+                                        lane, flag, (uint32_t)r << 16, &head, r == 0 ? 1 : 2);
         }
         store_row<2>(J, a, lane);
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);
