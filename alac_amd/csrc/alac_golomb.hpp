@@ -251,25 +251,38 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
     // lanes without a stream (n = 0: pad lanes, escape packets) do not count: in the unchecked blocks they code
     // whatever they load into state and bit words nobody reads (their wp points at a spare slot)
     const uint32_t nMinWave = wave_min_u32(n ? n : (idleFast ? 0xffffffffu : 0u));
-    auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
-        if (jb >= nMaxWave) return;
-        if (jb + B <= nMinWave) {  // every lane that has a stream owns the whole block
+    // Two copies of the block loop instead of a per-block choice inside one: the unchecked body (what runs for all
+    // but the last blocks of a wave) then fits the instruction cache — 48 unrolled symbols are ~36 KB, and with
+    // the checked variant in the same loop the body would be twice that (a 3 x 32-symbol body, 147 KB, was measured
+    // 3.5 x slower: the 64 KB instruction cache is a hard limit for these kernels).
+    auto codeFast = [&](const int32_t (&buf)[B]) {
 #pragma unroll
-            for (int s = 0; s < B; s++) golf_sym<WRITE, false, ZZ>(g, buf[s], true, bitSize, recip);
-        } else {
-#pragma unroll
-            for (int s = 0; s < B; s++) golf_sym<WRITE, true, ZZ>(g, buf[s], jb + s < n, bitSize, recip);
-        }
+        for (int s = 0; s < B; s++) golf_sym<WRITE, false, ZZ>(g, buf[s], true, bitSize, recip);
     };
+    auto codeChecked = [&](const int32_t (&buf)[B], uint32_t jb) {
+        if (jb >= nMaxWave) return;
+#pragma unroll
+        for (int s = 0; s < B; s++) golf_sym<WRITE, true, ZZ>(g, buf[s], jb + s < n, bitSize, recip);
+    };
+    const uint32_t fastEnd = (min(nMinWave, nMaxWave) / (3 * B)) * (3 * B);  // whole iterations every lane fully owns
     load(bufA, 0);
     load(bufB, B);
-    for (uint32_t jb = 0; jb < nMaxWave; jb += 3 * B) {
+    uint32_t jb = 0;
+    for (; jb < fastEnd; jb += 3 * B) {
         load(bufC, jb + 2 * B);
-        code(bufA, jb);
+        codeFast(bufA);
         load(bufA, jb + 3 * B);
-        code(bufB, jb + B);
+        codeFast(bufB);
         load(bufB, jb + 4 * B);
-        code(bufC, jb + 2 * B);
+        codeFast(bufC);
+    }
+    for (; jb < nMaxWave; jb += 3 * B) {
+        load(bufC, jb + 2 * B);
+        codeChecked(bufA, jb);
+        load(bufA, jb + 3 * B);
+        codeChecked(bufB, jb + B);
+        load(bufB, jb + 4 * B);
+        codeChecked(bufC, jb + 2 * B);
     }
     golf_finish<WRITE>(g, n > 0, recip);
 }
