@@ -58,6 +58,17 @@ def baseline_metric():
         return "encode Msamples/s (bit-exact) 44.1kHz/16-bit stereo, 1/2/4/8 GPU"
 
 
+def kernel_symbol(stage, fused, depth):
+    """HIP kernel behind a bench stage name (what rocprofv3's kernel stats list)."""
+    if stage == "lms_final" and any(f.startswith("lms_final") for f in fused):
+        return f"k_final_fused<{depth}, 2> (final pc_block pass || final dyn_comp, one launch)"
+    if stage == "lms_search1" and any(f.startswith("lms_search1") for f in fused):
+        return f"k_search1_fused<{depth}> (mixRes search passes || their dyn_comp counts, one launch)"
+    return {"lms_search1": "k_lms_search1", "golomb_count1": "k_gol_count1", "lms_search2": "k_lms_search2",
+            "golomb_count2": "k_gol_count2", "lms_final": "k_lms_final", "golomb_final": "k_gol_final",
+            "finalize_scan": "k_finalize + k_scan_sizes", "pack": "k_pack"}.get(stage, stage)
+
+
 def cpu_all_cores(fmt, packets):
     """The same CPU port on every host core at once (tools/cpu_all_cores.py: one worker process per core, run as
     a child process so that nothing here forks after the GPU is initialised).  SURVEY.md §8d."""
@@ -243,7 +254,8 @@ def main():
             "calls_timed": calls,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": dom, "kernel_ms": round(ms_dom, 4), "launches_per_step": n_dom,
+                         "kernel": dom, "kernel_symbol": kernel_symbol(dom, fused, args.bit_depth),
+                         "kernel_ms": round(ms_dom, 4), "launches_per_step": n_dom,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "dominant stage by measured time; the path is bound by serial integer "
                                  "recurrences (sign-LMS, Golomb mean tracker), not by HBM"},
