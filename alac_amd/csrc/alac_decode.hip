@@ -8,6 +8,7 @@
 //
 // Reference: ALACDecoder::Decode codec/ALACDecoder.cu:571-1002, fillWriteBuffer :497-563,
 // dyn_decomp codec/ag_dec.c:272-362, unpc_block codec/dp_dec.c:55-381.
+#include <cstdlib>
 #include "alac_dev.hpp"
 #include "alac_kernels.hpp"
 #include "alac_unpc.hpp"
@@ -467,12 +468,18 @@ hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32
                            hipStream_t st)
 {
     if (rows == 0) return hipSuccess;
-    if (decode)
+    // encode direction, 5 taps and more: one chain per half wave, taps across the lanes (alac_stage_taps.hip);
+    // fewer taps, or shapes outside that kernel's exact range: one lane per row
+    static const bool noTaps = [] { const char *v = getenv("ALAC_HIP_STAGE_TAPS"); return v && v[0] == '0'; }();
+    if (decode) {
         hipLaunchKernelGGL(k_unpc_block, dim3((rows + 63) / 64), dim3(64), 0, st, in, pc, rows, stride, num, coefs,
                            numactive, chanbits, denshift);
-    else
+    } else if (!noTaps && numactive >= 5 && pc_block_taps_ok(num, numactive, chanbits, denshift)) {
+        launch_pc_block_taps(in, pc, rows, stride, num, coefs, numactive, chanbits, denshift, st);
+    } else {
         hipLaunchKernelGGL(k_pc_block, dim3((rows + 63) / 64), dim3(64), 0, st, in, pc, rows, stride, num, coefs,
                            numactive, chanbits, denshift);
+    }
     return hipGetLastError();
 }
 

@@ -460,7 +460,6 @@ template <int DEPTH, int CH>
 __global__ __launch_bounds__(256) void k_pack(PackArgs A)
 {
     __shared__ uint32_t hdr[16];
-    __shared__ uint32_t hdrBits;
     const uint32_t p = blockIdx.x;
     const PacketRec rec = A.recs[p];
     const uint32_t N = rec.numSamples;
@@ -494,7 +493,6 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
                 for (uint32_t k = 0; k < rec.c[c].num; k++) h.put((uint16_t)rec.c[c].coefs[k], 16);
             }
         }
-        hdrBits = h.pos;
     }
     // the header LENGTH follows from the record alone, so the bulk copies below need not wait for its bits
     uint32_t hb = 3 + 4 + 12 + 4 + (partial ? 32u : 0u);

@@ -135,6 +135,10 @@ hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capW
 hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
                            int16_t *coefs, int32_t numactive, uint32_t chanbits, uint32_t denshift,
                            bool decode, hipStream_t st);
+// tap-parallel pc_block for any tap count (alac_stage_taps.hip); *_ok tells whether the shape is in its exact range
+bool pc_block_taps_ok(int32_t num, int32_t na, uint32_t chanbits, uint32_t denshift);
+void launch_pc_block_taps(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num, int16_t *coefs,
+                          int32_t na, uint32_t chanbits, uint32_t denshift, hipStream_t st);
 hipError_t launch_dyn_comp(uint32_t mb0, uint32_t pb, uint32_t kb, const int32_t *pc, uint32_t rows,
                            uint32_t stride, int32_t numSamples, int32_t bitSize, uint8_t *bits,
                            uint32_t bytesStride, uint32_t *numBits, hipStream_t st);

@@ -63,3 +63,27 @@ def test_dyn_comp_and_decomp(gpu_ctx, stage):
         gpu_ctx.synchronize()
         assert st.cpu().tolist() == [0, 0] and nb2.cpu().tolist() == [m["nbits"]] * 2, m
         assert np.array_equal(back[1, :n].cpu().numpy(), pc[:n]), m
+
+
+@pytest.mark.parametrize("na", [1, 2, 3, 5, 7, 9, 12, 15, 16, 17, 23, 30])
+def test_pc_block_any_tap_count_matches_oracle(gpu_ctx, oracle, na):
+    """the general loop of pc_block (dp_enc.c:341-387) for every tap count, incl. the tap-parallel kernel (>= 5
+    taps: one chain per half wave) — several rows so that both halves of a wave and a second wave are used"""
+    import torch
+    rng = np.random.default_rng(100 + na)
+    for chanbits, num in ((17, 700), (21, 333), (24, 64 + na), (16, na + 2)):
+        rows = 5
+        amp = 1 << (chanbits - 3)
+        t = np.arange(num + 40)
+        x = np.stack([(amp * np.sin(t * rng.uniform(0.01, 0.3)) + rng.integers(-amp // 8, amp // 8 + 1, num + 40)).astype(np.int32)
+                      for _ in range(rows)])
+        co0 = np.zeros((rows, 32), np.int16)
+        co0[:, :3] = [1216, -928, -64]
+        co0[:, 3:na] = rng.integers(-50, 50, (rows, max(na - 3, 0)))
+        co = torch.from_numpy(co0.copy()).cuda()
+        pc = gpu_ctx.pc_block(torch.from_numpy(x).cuda(), num, co, na, chanbits)
+        gpu_ctx.synchronize()
+        for r in range(rows):
+            want_pc, want_co = oracle.pc_block(x[r], num, co0[r], na, chanbits)
+            assert np.array_equal(pc[r, :num].cpu().numpy(), want_pc[:num]), (na, chanbits, num, r)
+            assert np.array_equal(co[r, :na].cpu().numpy(), want_co[:na]), (na, chanbits, num, r)
