@@ -422,16 +422,27 @@ static inline uint32_t bytes_per_sample(uint32_t bitDepth) { return bitDepth == 
 /* mix16 matrix_enc.cu:72-118, mix20 :120-183, mix24 :186-323, mix32 :330-425:
  * mixres != 0: u = (mixres*l + (2^mixbits - mixres)*r) >> mixbits, v = l - r; mixres == 0: u = l, v = r.
  * 24/32-bit with bytesShifted: low bytes go to shiftUV interleaved, then l,r >>= shift. */
+static void mix_strided(const uint8_t *pcm, uint32_t stride, uint32_t bitDepth, int32_t *u, int32_t *v,
+                        int32_t numSamples, int32_t mixbits, int32_t mixres, uint16_t *shiftUV, int32_t bytesShifted);
+
 void oalac_mix(const uint8_t *pcm, uint32_t bitDepth, int32_t *u, int32_t *v, int32_t numSamples,
                int32_t mixbits, int32_t mixres, uint16_t *shiftUV, int32_t bytesShifted)
+{
+    mix_strided(pcm, 2, bitDepth, u, v, numSamples, mixbits, mixres, shiftUV, bytesShifted);
+}
+
+/* `stride` = interleaved channels of the input (the mixNN stride argument, matrix_enc.cu:72): the pair is
+ * channels 0 and 1 at `pcm` of a stride-channel frame */
+static void mix_strided(const uint8_t *pcm, uint32_t stride, uint32_t bitDepth, int32_t *u, int32_t *v,
+                        int32_t numSamples, int32_t mixbits, int32_t mixres, uint16_t *shiftUV, int32_t bytesShifted)
 {
     uint32_t bps = bytes_per_sample(bitDepth);
     int32_t shift = bytesShifted * 8;
     uint32_t mask = (1u << shift) - 1;
     int32_t m2 = (1 << mixbits) - mixres;
     for (int32_t z = 0; z < numSamples; z++) {
-        int32_t l = load_sample(pcm + (size_t)(2 * z) * bps, bitDepth);
-        int32_t r = load_sample(pcm + (size_t)(2 * z + 1) * bps, bitDepth);
+        int32_t l = load_sample(pcm + ((size_t)z * stride) * bps, bitDepth);
+        int32_t r = load_sample(pcm + ((size_t)z * stride + 1) * bps, bitDepth);
         if (bytesShifted != 0) {
             shiftUV[2 * z + 0] = (uint16_t)((uint32_t)l & mask);
             shiftUV[2 * z + 1] = (uint16_t)((uint32_t)r & mask);
@@ -473,9 +484,20 @@ static inline void store_sample(uint8_t *p, uint32_t bitDepth, int32_t x)
 }
 
 /* gpu_unmix16 ALACDecoder.cu:193-223, unmix20 :227-278, unmix24 :282-338, unmix32 :344-383 */
+static void unmix_strided(const int32_t *u, const int32_t *v, uint8_t *pcm, uint32_t stride, uint32_t bitDepth,
+                          int32_t numSamples, int32_t mixbits, int32_t mixres, const uint16_t *shiftUV,
+                          int32_t bytesShifted);
+
 void oalac_unmix(const int32_t *u, const int32_t *v, uint8_t *pcm, uint32_t bitDepth,
                  int32_t numSamples, int32_t mixbits, int32_t mixres, const uint16_t *shiftUV,
                  int32_t bytesShifted)
+{
+    unmix_strided(u, v, pcm, 2, bitDepth, numSamples, mixbits, mixres, shiftUV, bytesShifted);
+}
+
+static void unmix_strided(const int32_t *u, const int32_t *v, uint8_t *pcm, uint32_t stride, uint32_t bitDepth,
+                          int32_t numSamples, int32_t mixbits, int32_t mixres, const uint16_t *shiftUV,
+                          int32_t bytesShifted)
 {
     uint32_t bps = bytes_per_sample(bitDepth);
     int32_t shift = bytesShifted * 8;
@@ -492,8 +514,8 @@ void oalac_unmix(const int32_t *u, const int32_t *v, uint8_t *pcm, uint32_t bitD
             l = (int32_t)(((uint32_t)l << shift) | shiftUV[2 * z + 0]);
             r = (int32_t)(((uint32_t)r << shift) | shiftUV[2 * z + 1]);
         }
-        store_sample(pcm + (size_t)(2 * z) * bps, bitDepth, l);
-        store_sample(pcm + (size_t)(2 * z + 1) * bps, bitDepth, r);
+        store_sample(pcm + ((size_t)z * stride) * bps, bitDepth, l);
+        store_sample(pcm + ((size_t)z * stride + 1) * bps, bitDepth, r);
     }
 }
 
@@ -530,7 +552,7 @@ oalac_encoder *oalac_encoder_new(uint32_t frameSize, uint32_t bitDepth, uint32_t
                                  uint32_t sampleRate)
 {
     if (!(bitDepth == 16 || bitDepth == 20 || bitDepth == 24 || bitDepth == 32)) return NULL;
-    if (numChannels < 1 || numChannels > 2 || frameSize == 0) return NULL;
+    if (numChannels < 1 || numChannels > OALAC_MAX_CHANNELS || frameSize == 0) return NULL;
     oalac_encoder *e = (oalac_encoder *)calloc(1, sizeof(*e));
     if (!e) return NULL;
     e->frameSize = frameSize;
@@ -616,6 +638,24 @@ uint32_t oalac_magic_cookie(const oalac_encoder *e, uint8_t *c)
     return 24;
 }
 
+/* GetMagicCookie for any channel count, ALACEncoder.cu:1109-1140: above 2 channels the 24-byte config is followed
+ * by a 12-byte 'chan' atom header (size byte 24 in [3]) and an ALACAudioChannelLayout {tag, bitmap 0, descriptions 0}.
+ * The fork stores the layout tag WITHOUT the big-endian swap (:1120 has no Swap32NtoB), i.e. in host order = little
+ * endian here; restated as the fork does it.  buf must hold 48 bytes. */
+uint32_t oalac_magic_cookie_full(const oalac_encoder *e, uint8_t *c)
+{
+    static const uint32_t tags[OALAC_MAX_CHANNELS] = {(100u << 16) | 1, (101u << 16) | 2, (113u << 16) | 3, (116u << 16) | 4,
+                                                      (120u << 16) | 5, (124u << 16) | 6, (142u << 16) | 7, (127u << 16) | 8};
+    oalac_magic_cookie(e, c);
+    if (e->numChannels <= 2) return 24;
+    memset(c + 24, 0, 24);
+    c[27] = 24;
+    memcpy(c + 28, "chan", 4);
+    uint32_t t = tags[e->numChannels - 1];
+    c[36] = (uint8_t)t; c[37] = (uint8_t)(t >> 8); c[38] = (uint8_t)(t >> 16); c[39] = (uint8_t)(t >> 24);
+    return 48;
+}
+
 static inline uint32_t bytes_shifted_for(uint32_t bitDepth)
 {
     return bitDepth == 32 ? 2 : bitDepth >= 24 ? 1 : 0; /* :327-332 */
@@ -623,7 +663,7 @@ static inline uint32_t bytes_shifted_for(uint32_t bitDepth)
 
 /* EncodeStereoEscape, ALACEncoder.cu:749-806 */
 static void encode_stereo_escape(oalac_encoder *e, uint8_t *out, uint64_t *pos, const uint8_t *pcm,
-                                 uint32_t numSamples)
+                                 uint32_t stride, uint32_t numSamples)
 {
     uint32_t partial = (numSamples == e->frameSize) ? 0 : 1;
     uint32_t bps = bytes_per_sample(e->bitDepth);
@@ -632,16 +672,15 @@ static void encode_stereo_escape(oalac_encoder *e, uint8_t *out, uint64_t *pos, 
     if (partial) oalac_put_bits(out, pos, numSamples, 32);
     for (uint32_t i = 0; i < numSamples * 2; i++) {
         /* 16/32: raw words; 20/24: de-interleave via mixNN(mixres 0, no shift) then bitDepth bits */
-        int32_t x = load_sample(pcm + (size_t)i * bps, e->bitDepth);
+        int32_t x = load_sample(pcm + ((size_t)(i >> 1) * stride + (i & 1)) * bps, e->bitDepth);
         oalac_put_bits(out, pos, (uint32_t)x, e->bitDepth);
     }
 }
 
 /* EncodeStereo, ALACEncoder.cu:290-558 */
 static int32_t encode_stereo(oalac_encoder *e, uint8_t *out, uint64_t *pos, const uint8_t *pcm,
-                             uint32_t numSamples)
+                             uint32_t stride, uint32_t ch, uint32_t numSamples)
 {
-    const uint32_t ch = 0;
     uint64_t startPos = *pos;
     uint32_t bytesShifted = bytes_shifted_for(e->bitDepth);
     uint32_t chanBits = e->bitDepth - bytesShifted * 8 + 1;
@@ -660,8 +699,8 @@ static int32_t encode_stereo(oalac_encoder *e, uint8_t *out, uint64_t *pos, cons
     for (int32_t mixRes = 0; mixRes <= maxRes; mixRes++) {
         /* the search-form kernels apply the shift but do not keep the low bytes (:1216-1310);
          * shiftUV written here is overwritten by the full mix below before anything reads it */
-        oalac_mix(pcm, e->bitDepth, e->mixU, e->mixV, (int32_t)(numSamples / dilate), mixBits, mixRes,
-                  e->shiftUV, (int32_t)bytesShifted);
+        mix_strided(pcm, stride, e->bitDepth, e->mixU, e->mixV, (int32_t)(numSamples / dilate), mixBits, mixRes,
+                    e->shiftUV, (int32_t)bytesShifted);
         e->hooks.pc_block(e->mixU, e->predU, (int32_t)(numSamples / dilate), e->coefsU[ch][7], 8, chanBits, OALAC_DENSHIFT);
         e->hooks.pc_block(e->mixV, e->predV, (int32_t)(numSamples / dilate), e->coefsV[ch][7], 8, chanBits, OALAC_DENSHIFT);
         uint64_t wpos = 0;
@@ -677,8 +716,8 @@ static int32_t encode_stereo(oalac_encoder *e, uint8_t *out, uint64_t *pos, cons
     int32_t mixRes = bestRes;
 
     /* :385-415 full mix with the chosen mixRes (+ shift-off bytes) */
-    oalac_mix(pcm, e->bitDepth, e->mixU, e->mixV, (int32_t)numSamples, mixBits, mixRes, e->shiftUV,
-              (int32_t)bytesShifted);
+    mix_strided(pcm, stride, e->bitDepth, e->mixU, e->mixV, (int32_t)numSamples, mixBits, mixRes, e->shiftUV,
+                (int32_t)bytesShifted);
 
     /* :418-452 numUV search: 8 converge passes over numSamples/32, then dyn_comp over
      * numSamples/8 — entries [numSamples/32, numSamples/8) of the predictor buffers still hold
@@ -754,21 +793,21 @@ static int32_t encode_stereo(oalac_encoder *e, uint8_t *out, uint64_t *pos, cons
     }
     if (doEscape) {
         e->info[0] = 1;
-        encode_stereo_escape(e, out, pos, pcm, numSamples);
+        encode_stereo_escape(e, out, pos, pcm, stride, numSamples);
     }
     return OALAC_noErr;
 }
 
 /* mono input widening: gpu_copyNNToPredictor, ALACEncoder.cu:1312-1382 (the fork's indexing of
  * those kernels is broken; the intended per-sample math is what is restated) */
-static void copy_to_predictor(const uint8_t *pcm, uint32_t bitDepth, int32_t *out, uint16_t *shiftBuf,
+static void copy_to_predictor(const uint8_t *pcm, uint32_t stride, uint32_t bitDepth, int32_t *out, uint16_t *shiftBuf,
                               uint32_t numSamples, uint32_t bytesShifted)
 {
     uint32_t bps = bytes_per_sample(bitDepth);
     uint32_t shift = bytesShifted * 8;
     uint32_t mask = (1u << shift) - 1;
     for (uint32_t z = 0; z < numSamples; z++) {
-        int32_t val = load_sample(pcm + (size_t)z * bps, bitDepth);
+        int32_t val = load_sample(pcm + (size_t)z * stride * bps, bitDepth);
         if (bytesShifted) {
             shiftBuf[z] = (uint16_t)((uint32_t)val & mask);
             val >>= shift;
@@ -781,9 +820,8 @@ static void copy_to_predictor(const uint8_t *pcm, uint32_t bitDepth, int32_t *ou
  * escape packet restated here is the one the reference's own decoder parses
  * (ALACDecoder.cu:697-727): 12b 0, 4b (partial<<3)|1, [32b N], N samples of bitDepth bits. */
 static int32_t encode_mono(oalac_encoder *e, uint8_t *out, uint64_t *pos, const uint8_t *pcm,
-                           uint32_t numSamples)
+                           uint32_t stride, uint32_t ch, uint32_t numSamples)
 {
-    const uint32_t ch = 0;
     uint64_t startPos = *pos;
     uint32_t bytesShifted = bytes_shifted_for(e->bitDepth);
     uint32_t shift = bytesShifted * 8;
@@ -794,7 +832,7 @@ static int32_t encode_mono(oalac_encoder *e, uint8_t *out, uint64_t *pos, const 
     uint32_t bits1;
     int32_t status;
 
-    copy_to_predictor(pcm, e->bitDepth, e->mixU, e->shiftUV, numSamples, bytesShifted);
+    copy_to_predictor(pcm, stride, e->bitDepth, e->mixU, e->shiftUV, numSamples, bytesShifted);
 
     /* :874-905 */
     uint32_t minBits = 1u << 31, bestU = 4;
@@ -854,9 +892,26 @@ static int32_t encode_mono(oalac_encoder *e, uint8_t *out, uint64_t *pos, const 
         oalac_put_bits(out, pos, (partial << 3) | 1, 4);
         if (partial) oalac_put_bits(out, pos, numSamples, 32);
         for (uint32_t i = 0; i < numSamples; i++)
-            oalac_put_bits(out, pos, (uint32_t)load_sample(pcm + (size_t)i * bps, e->bitDepth), e->bitDepth);
+            oalac_put_bits(out, pos, (uint32_t)load_sample(pcm + (size_t)i * stride * bps, e->bitDepth), e->bitDepth);
     }
     return OALAC_noErr;
+}
+
+/* sChannelMaps, ALACEncoder.cu:97-107 */
+static const uint32_t k_channel_maps[OALAC_MAX_CHANNELS] = {
+    0,
+    1,
+    (1u << 3) | 0,
+    (0u << 9) | (1u << 3) | 0,
+    (1u << 9) | (1u << 3) | 0,
+    (0u << 15) | (1u << 9) | (1u << 3) | 0,
+    (0u << 18) | (0u << 15) | (1u << 9) | (1u << 3) | 0,
+    (0u << 21) | (1u << 15) | (1u << 9) | (1u << 3) | 0,
+};
+
+uint32_t oalac_channel_map(uint32_t numChannels)
+{
+    return (numChannels >= 1 && numChannels <= OALAC_MAX_CHANNELS) ? k_channel_maps[numChannels - 1] : 0;
 }
 
 /* Encode, ALACEncoder.cu:973-1057 */
@@ -869,11 +924,34 @@ int32_t oalac_encode_packet(oalac_encoder *e, const uint8_t *pcm, uint32_t numSa
     if (e->numChannels == 2) {
         oalac_put_bits(out, &pos, 1 /* ID_CPE */, 3);
         oalac_put_bits(out, &pos, 0, 4);
-        status = encode_stereo(e, out, &pos, pcm, numSamples);
-    } else {
+        status = encode_stereo(e, out, &pos, pcm, 2, 0, numSamples);
+    } else if (e->numChannels == 1) {
         oalac_put_bits(out, &pos, 0 /* ID_SCE */, 3);
         oalac_put_bits(out, &pos, 0, 4);
-        status = encode_mono(e, out, &pos, pcm, numSamples);
+        status = encode_mono(e, out, &pos, pcm, 1, 0, numSamples);
+    } else {
+        /* > 2 channels: the element loop of Apple's encoder that the fork dropped, driven by the
+         * fork's own table sChannelMaps (ALACEncoder.cu:97-107: 3 bits per channel index, ID_SCE = 0 / ID_CPE = 1;
+         * the LFE positions of the 5.1 .. 7.1 layouts carry ID_SCE in that table).  Every element type counts its
+         * own 4-bit instance tag; element k uses the coefficient rows of its first channel and reads its samples
+         * at that channel of the numChannels-interleaved frame.  Checked against the decoder's element loop
+         * (ALACDecoder.cu:600-990), which is the reference code that parses it. */
+        uint32_t bps = bytes_per_sample(e->bitDepth);
+        uint32_t monoTag = 0, stereoTag = 0;
+        status = OALAC_noErr;
+        for (uint32_t ci = 0; ci < e->numChannels && status == OALAC_noErr;) {
+            uint32_t tag = (k_channel_maps[e->numChannels - 1] >> (ci * 3)) & 7u;
+            oalac_put_bits(out, &pos, tag, 3);
+            if (tag == 1) {
+                oalac_put_bits(out, &pos, stereoTag++, 4);
+                status = encode_stereo(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples);
+                ci += 2;
+            } else {
+                oalac_put_bits(out, &pos, monoTag++, 4);
+                status = encode_mono(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples);
+                ci += 1;
+            }
+        }
     }
     if (status) return status;
     oalac_put_bits(out, &pos, 7 /* ID_END */, 3);
@@ -1078,10 +1156,10 @@ int32_t oalac_decode_packet(oalac_decoder *d, const uint8_t *packet, uint32_t pk
                 }
                 bytesShifted = 0;
             }
-            if (numChannels == 2) {
-                oalac_unmix(d->mixU, d->mixV, pcmOut, d->bitDepth, (int32_t)numSamples, mixBits, mixRes, d->shiftBuf, (int32_t)bytesShifted);
-            } else
-                return OALAC_UnimplementedError;
+            /* unmixNN(u, v, out + channelIndex, stride numChannels, ...): the fork's gpu_unmixNN handles the
+             * stereo file only; the strided form is the upstream call the element loop was written for */
+            unmix_strided(d->mixU, d->mixV, pcmOut + (size_t)channelIndex * bps, numChannels, d->bitDepth,
+                          (int32_t)numSamples, mixBits, mixRes, d->shiftBuf, (int32_t)bytesShifted);
             channelIndex += 2;
             *outNumSamples = numSamples;
             break;
@@ -1112,6 +1190,11 @@ int32_t oalac_decode_packet(oalac_decoder *d, const uint8_t *packet, uint32_t pk
         if (channelIndex >= numChannels) break;
     }
 no_more:
+    /* channels the packet did not carry are zero (ALACDecoder.cu:971-998; the fill is commented out in the fork,
+     * upstream performs it) */
+    for (; channelIndex < numChannels; channelIndex++)
+        for (uint32_t i = 0; i < numSamples; i++)
+            store_sample(pcmOut + ((size_t)i * numChannels + channelIndex) * bps, d->bitDepth, 0);
     return status;
 }
 

@@ -102,6 +102,11 @@ void oalac_encoder_last_info(const oalac_encoder *e, uint32_t *info6);
 /* 24-byte magic cookie: codec/ALACEncoder.cu:1082-1140 (<=2 channels) */
 uint32_t oalac_magic_cookie(const oalac_encoder *e, uint8_t *cookie24);
 
+/* 24 or (numChannels > 2) 48 bytes: config + 'chan' atom + channel layout, codec/ALACEncoder.cu:1109-1140 */
+uint32_t oalac_magic_cookie_full(const oalac_encoder *e, uint8_t *cookie48);
+/* sChannelMaps[numChannels - 1], codec/ALACEncoder.cu:97-107 (3 bits per channel index: 0 = ID_SCE, 1 = ID_CPE) */
+uint32_t oalac_channel_map(uint32_t numChannels);
+
 /* encode `numPackets` consecutive packets; if segmentPackets > 0 the state is reset every
  * segmentPackets packets (independent segments), 0 = one chained stream.  Sizes go to
  * packetBytes[numPackets]; packets are written back to back into out. Returns total bytes or <0. */

@@ -79,6 +79,10 @@ class Oracle:
         lib.oalac_encoder_last_info.argtypes = [C.c_void_p, u32p]
         lib.oalac_magic_cookie.argtypes = [C.c_void_p, u8p]
         lib.oalac_magic_cookie.restype = C.c_uint32
+        lib.oalac_magic_cookie_full.argtypes = [C.c_void_p, u8p]
+        lib.oalac_magic_cookie_full.restype = C.c_uint32
+        lib.oalac_channel_map.argtypes = [C.c_uint32]
+        lib.oalac_channel_map.restype = C.c_uint32
         lib.oalac_encode_stream.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_uint32, u8p,
                                             C.c_uint64, u32p]
         lib.oalac_encode_stream.restype = C.c_int64
@@ -193,9 +197,9 @@ class OracleEncoder:
         self.lib.oalac_encoder_set_state(self.h, _ptr(s, i16p))
 
     def cookie(self):
-        c = np.zeros(24, np.uint8)
-        self.lib.oalac_magic_cookie(self.h, _ptr(c, u8p))
-        return c
+        c = np.zeros(48, np.uint8)
+        n = self.lib.oalac_magic_cookie_full(self.h, _ptr(c, u8p))
+        return c[:n].copy()
 
     def encode_packet(self, pcm_bytes, num_samples):
         pcm = np.concatenate([np.ascontiguousarray(pcm_bytes, np.uint8).ravel(),
@@ -236,7 +240,11 @@ class OracleDecoder:
         self._hooks = hooks
         if self.h and hooks is not None:
             self.lib.oalac_decoder_set_hooks(self.h, C.byref(hooks))
-        self.frame = int.from_bytes(bytes(ck[-24:][0:4]), "big") if ck.size >= 24 else 0
+        cfg = bytes(ck)
+        for atom in (b"frma", b"alac"):  # legacy wrappers, codec/ALACDecoder.cu:123-134
+            if len(cfg) >= 12 and cfg[4:8] == atom:
+                cfg = cfg[12:]
+        self.frame = int.from_bytes(cfg[0:4], "big") if len(cfg) >= 24 else 0
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -305,3 +313,43 @@ def read_wav(path):
             return fmt + (data,)
         pos += 8 + sz + (sz & 1)
     raise ValueError("no data chunk")
+
+
+# ---- > 2 channels: test data and the element view of a packet ------------------------------------
+
+def channel_elements(o, channels):
+    """[(first channel, channels in the element)] in packet order, from sChannelMaps (codec/ALACEncoder.cu:97-107)."""
+    m, out, ci = o.lib.oalac_channel_map(channels), [], 0
+    while ci < channels:
+        n = 2 if ((m >> (3 * ci)) & 7) == 1 else 1
+        out.append((ci, n))
+        ci += n
+    return out
+
+
+def interleave_channels(parts, depth):
+    """parts: list of (pcm bytes, channels) with the same number of frames -> one interleaved byte array."""
+    bps = {16: 2, 20: 3, 24: 3, 32: 4}[depth]
+    cols = [np.ascontiguousarray(p, np.uint8).reshape(-1, c * bps) for p, c in parts]
+    return np.concatenate(cols, axis=1).reshape(-1)
+
+
+def take_channels(pcm, channels, first, count, depth):
+    bps = {16: 2, 20: 3, 24: 3, 32: 4}[depth]
+    a = np.ascontiguousarray(pcm, np.uint8).reshape(-1, channels * bps)
+    return np.ascontiguousarray(a[:, first * bps:(first + count) * bps]).reshape(-1)
+
+
+def splice_elements(packets):
+    """packets: list of (complete one-element packet bytes, instance tag).  Returns the packet that carries all the
+    elements: every element's bits up to its ID_END (the last set bit run '111' before the zero padding), the 4-bit
+    instance tag replaced, then one ID_END and the byte alignment (codec/ALACEncoder.cu:1034-1039)."""
+    bits = []
+    for pk, tag in packets:
+        b = np.unpackbits(np.ascontiguousarray(pk, np.uint8))
+        last = int(np.nonzero(b)[0][-1])  # last bit of ID_END
+        e = b[:last - 2].copy()
+        e[3:7] = [(tag >> 3) & 1, (tag >> 2) & 1, (tag >> 1) & 1, tag & 1]
+        bits.append(e)
+    bits.append(np.array([1, 1, 1], np.uint8))
+    return np.packbits(np.concatenate(bits))

@@ -250,3 +250,66 @@ def test_state_carry_equals_chained(oracle):
     e2.set_state(e1.get_state())
     b, _ = e2.encode_stream(pcm[3 * fmt.packet_bytes:], 3 * 4096, 0)
     assert np.array_equal(np.concatenate([a, b]), whole)
+
+
+# ---- > 2 channels: the element loop ---------------------------------------------------
+
+def _multichannel_pcm(o, channels, depth, first, packets):
+    from oracle_lib import channel_elements, interleave_channels
+    parts = []
+    for k, (ci, n) in enumerate(channel_elements(o, channels)):
+        parts.append((alac_amd.synth_pcm(first + 16 * k, packets, alac_amd.make_format(4096, depth, n)), n))
+    return interleave_channels(parts, depth)
+
+
+@pytest.mark.parametrize("channels", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("depth", [16, 24])
+def test_multichannel_packets_are_spliced_elements(oracle, channels, depth):
+    """a packet of a > 2-channel stream == the mono / stereo packets of its channel groups (each chained through its
+    own coefficient rows) joined at bit granularity with counted instance tags and one ID_END; and it decodes back
+    to the input through the decoder's element loop (codec/ALACDecoder.cu:600-990)."""
+    from oracle_lib import channel_elements, splice_elements, take_channels
+    fmt = alac_amd.make_format(4096, depth, channels)
+    npk, total = 5, 4 * 4096 + 1000
+    pcm = _multichannel_pcm(oracle, channels, depth, 0, npk)
+    stream, sizes = oracle.encoder(4096, depth, channels).encode_stream(pcm, total, 0)
+    elems = channel_elements(oracle, channels)
+    assert sum(n for _, n in elems) == channels
+    sub = []
+    for ci, n in elems:
+        s, z = oracle.encoder(4096, depth, n).encode_stream(take_channels(pcm, channels, ci, n, depth), total, 0)
+        sub.append((s, np.concatenate([[0], np.cumsum(z)]).astype(np.int64)))
+    enc = oracle.encoder(4096, depth, channels)
+    cookie = enc.cookie()
+    assert len(cookie) == 48 and bytes(cookie[28:32]) == b"chan" and cookie[27] == 24 and cookie[9] == channels
+    dec = oracle.decoder(cookie)
+    off = 0
+    for p in range(npk):
+        tags, parts = {1: 0, 2: 0}, []
+        for (ci, n), (s, o) in zip(elems, sub):
+            parts.append((s[o[p]:o[p + 1]], tags[n]))
+            tags[n] += 1
+        want = splice_elements(parts)
+        got = stream[off:off + int(sizes[p])]
+        assert np.array_equal(got, want), (channels, depth, p)
+        ns = 4096 if p < 4 else 1000
+        st, out, n = dec.decode_packet(got, fmt.bytes_per_frame)
+        assert st == 0 and n == ns
+        assert np.array_equal(out, pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns * fmt.bytes_per_frame])
+        off += int(sizes[p])
+
+
+def test_multichannel_over_reference_stages(oracle, ref):
+    """the element loop driving the reference's own pc_block / dyn_comp / dyn_decomp / unpc_block objects"""
+    H = ref.hooks()
+    pcm = _multichannel_pcm(oracle, 6, 16, 3, 3)
+    fmt = alac_amd.make_format(4096, 16, 6)
+    a, za = oracle.encoder(4096, 16, 6).encode_stream(pcm, 3 * 4096, 0)
+    b, zb = oracle.encoder(4096, 16, 6, hooks=H).encode_stream(pcm, 3 * 4096, 0)
+    assert np.array_equal(a, b) and np.array_equal(za, zb)
+    dec = oracle.decoder(oracle.encoder(4096, 16, 6).cookie(), hooks=H)
+    off = 0
+    for p, z in enumerate(za):
+        st, out, n = dec.decode_packet(a[off:off + int(z)], fmt.bytes_per_frame)
+        assert st == 0 and np.array_equal(out, pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes])
+        off += int(z)
