@@ -53,6 +53,9 @@ SIGNATURES = {
     "alac_hip_num_stages": (_u32, []),
     "alac_hip_stage_name": (C.c_char_p, [_u32]),
     "alac_hip_magic_cookie": (_u32, [C.POINTER(Format), _u32, _u32, _vp]),
+    "alac_hip_magic_cookie_size": (_u32, [C.POINTER(Format)]),
+    "alac_hip_magic_cookie_full": (_u32, [C.POINTER(Format), _u32, _u32, _vp, _u32]),
+    "alac_hip_state_int16": (_u32, [C.POINTER(Format)]),
     "alac_hip_decode_workspace_bytes": (_u64, [C.POINTER(Format), _u32]),
     "alac_hip_decode": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _vp]),
     "alac_hip_format_from_cookie": (_i32, [_vp, _u32, C.POINTER(Format)]),
@@ -204,10 +207,10 @@ class Context:
         return n.value, {self.lib.alac_hip_stage_name(i).decode(): (float(ms[i]), int(ln[i])) for i in range(ns)}
 
     def magic_cookie(self, fmt, max_frame_bytes=0, avg_bit_rate=0):
-        c = np.zeros(24, np.uint8)
-        n = self.lib.alac_hip_magic_cookie(C.byref(fmt), max_frame_bytes, avg_bit_rate, c.ctypes.data)
-        assert n == 24
-        return c
+        c = np.zeros(48, np.uint8)
+        n = self.lib.alac_hip_magic_cookie_full(C.byref(fmt), max_frame_bytes, avg_bit_rate, c.ctypes.data, 48)
+        assert n == self.lib.alac_hip_magic_cookie_size(C.byref(fmt)) and n in (24, 48)
+        return c[:n].copy()
 
     # ---- decode ----------------------------------------------------------------------------
     def decode(self, cookie, stream, offsets, num_packets):

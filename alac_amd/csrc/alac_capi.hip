@@ -48,7 +48,7 @@ bool format_ok(const alac_hip_format *f)
 {
     if (!f) return false;
     if (!(f->bit_depth == 16 || f->bit_depth == 20 || f->bit_depth == 24 || f->bit_depth == 32)) return false;
-    if (f->num_channels < 1 || f->num_channels > 2) return false;
+    if (f->num_channels < 1 || f->num_channels > kMaxChannels) return false;
     if (f->frame_size == 0 || f->frame_size > (1u << 20)) return false;
     return true;
 }
@@ -125,8 +125,60 @@ bool use_lane_encoder()
     return v != 0;
 }
 
+// > 2 channels: the mono / stereo pipeline once per element over a gathered copy of its channels, then the splice
+// (alac_multichannel.hip)
+alac_hip_format element_format(const alac_hip_format *f, uint32_t channels)
+{
+    alac_hip_format e = *f;
+    e.num_channels = channels;
+    return e;
+}
+
+uint64_t max_output_bytes(const alac_hip_format *fmt, uint32_t num_packets)
+{
+    // escape elements: 7 + 16 + 32 + N*ch*depth bits each, + ID_END, rounded up; +8 so word stores may overhang
+    const uint64_t elems = fmt->num_channels > 2 ? fmt->num_channels : 1;
+    const uint64_t per = ((uint64_t)fmt->frame_size * fmt->num_channels * fmt->bit_depth + 55 * elems + 3 + 7) / 8;
+    return align_up(per * num_packets + 8, 16);
+}
+
+struct McLayout {
+    uint32_t numElements;
+    McElement el[kMaxChannels];
+    uint64_t gather, sub, subBytes, out[kMaxChannels], outCap[kMaxChannels], sizes[kMaxChannels], offs[kMaxChannels];
+    uint64_t elemBits, total;
+};
+
+McLayout mc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t numSegments)
+{
+    McLayout M;
+    M.numElements = channel_elements(f->num_channels, M.el);
+    const alac_hip_format f1 = element_format(f, 1), f2 = element_format(f, 2);
+    uint64_t off = 0;
+    M.gather = off;
+    off = align_up(off + (uint64_t)numPackets * f->frame_size * 2 * bytes_per_sample(f->bit_depth) + 64, 256);
+    M.sub = off;
+    const uint64_t s1 = enc_layout(&f1, numPackets, numSegments).total, s2 = enc_layout(&f2, numPackets, numSegments).total;
+    M.subBytes = s1 > s2 ? s1 : s2;
+    off = align_up(off + M.subBytes, 256);
+    for (uint32_t e = 0; e < M.numElements; e++) {
+        M.outCap[e] = max_output_bytes(M.el[e].channels == 2 ? &f2 : &f1, numPackets);
+        M.out[e] = off;
+        off = align_up(off + M.outCap[e] + 16, 256);
+        M.sizes[e] = off;
+        off = align_up(off + (uint64_t)numPackets * 4, 256);
+        M.offs[e] = off;
+        off = align_up(off + ((uint64_t)numPackets + 1) * 8, 256);
+    }
+    M.elemBits = off;
+    off = align_up(off + (uint64_t)M.numElements * numPackets * 4, 256);
+    M.total = off;
+    return M;
+}
+
 struct DecLayout {
     uint64_t recs, resid, words, capWords, prog, total;
+    uint32_t maxElems;
 };
 
 DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
@@ -134,12 +186,13 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
     DecLayout L;
     uint64_t off = 0;
     L.recs = off;
-    off = align_up(off + (uint64_t)numPackets * sizeof(DecRec), 256);
+    L.maxElems = f->num_channels > 2 ? f->num_channels : 1;
+    off = align_up(off + (uint64_t)numPackets * L.maxElems * sizeof(DecRec), 256);
     L.resid = off;
     off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
     // the stream re-staged as MSB-first words, zero padded (alac_decode_v1.hip): every packet at its largest
     L.words = off;
-    L.capWords = ((uint64_t)numPackets * alac_hip_encode_max_output_bytes(f, 1) + 3) / 4 + 64;
+    L.capWords = f->num_channels > 2 ? 0 : ((uint64_t)numPackets * max_output_bytes(f, 1) + 3) / 4 + 64;
     off = align_up(off + L.capWords * 4, 256);
     L.prog = off;
     off = align_up(off + (uint64_t)numPackets * 8, 256);
@@ -240,16 +293,35 @@ void *alac_hip_stream(const alac_hip_ctx *ctx) { return ctx ? (void *)ctx->strea
 uint64_t alac_hip_encode_workspace_bytes(const alac_hip_format *fmt, uint32_t num_packets, uint32_t num_segments)
 {
     if (!format_ok(fmt)) return 0;
+    if (fmt->num_channels > 2) return mc_layout(fmt, num_packets, num_segments ? num_segments : num_packets).total;
     return enc_layout(fmt, num_packets, num_segments ? num_segments : num_packets).total;
+}
+
+uint32_t alac_hip_state_int16(const alac_hip_format *fmt)
+{
+    if (!format_ok(fmt)) return 0;
+    McElement el[kMaxChannels];
+    return ALAC_HIP_STATE_INT16 * (fmt->num_channels > 2 ? channel_elements(fmt->num_channels, el) : 1);
 }
 
 uint64_t alac_hip_encode_max_output_bytes(const alac_hip_format *fmt, uint32_t num_packets)
 {
     if (!format_ok(fmt)) return 0;
-    // escape element: 7 + 16 + 32 + N*ch*depth + 3 bits, rounded up; +4 so word stores may overhang
-    const uint64_t per = ((uint64_t)fmt->frame_size * fmt->num_channels * fmt->bit_depth + 58 + 7) / 8;
-    return align_up(per * num_packets + 8, 16);
+    return max_output_bytes(fmt, num_packets);
 }
+
+static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                               const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
+                               uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
+                               uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
+                               uint32_t *d_packet_bytes, uint64_t *d_packet_offsets);
+
+// one mono / stereo batch; `timed` = this call may consume a slot of the armed stage timing
+static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                           const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
+                           uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
+                           uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
+                           uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, bool timed);
 
 int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
                         const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
@@ -259,6 +331,64 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
 {
     if (!ctx) return ALAC_HIP_ParamError;
     if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
+    if (fmt->num_channels > 2)
+        return encode_elements(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, d_state, state_in,
+                               d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets);
+    return encode_core(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, d_state, state_in,
+                       d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets, true);
+}
+
+static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                               const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
+                               uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
+                               uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
+                               uint32_t *d_packet_bytes, uint64_t *d_packet_offsets)
+{
+    if (num_packets == 0) return ALAC_HIP_noErr;
+    if (!d_pcm || !d_workspace || !d_out || !d_packet_bytes || !d_packet_offsets)
+        return fail(ctx, ALAC_HIP_ParamError, "null buffer");
+    if (!d_seg_first) num_segments = num_packets;
+    if (num_segments == 0 || num_segments > num_packets) return fail(ctx, ALAC_HIP_ParamError, "bad segment count");
+    if (((uintptr_t)d_workspace & 255)) return fail(ctx, ALAC_HIP_ParamError, "misaligned workspace (256 B)");
+    const McLayout M = mc_layout(fmt, num_packets, num_segments);
+    if (workspace_bytes < M.total) return fail(ctx, ALAC_HIP_ParamError, "workspace too small");
+    if (out_capacity < max_output_bytes(fmt, num_packets))
+        return fail(ctx, ALAC_HIP_ParamError, "output capacity below alac_hip_encode_max_output_bytes");
+    if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
+    uint8_t *ws = (uint8_t *)d_workspace;
+    McSpliceArgs sa;
+    sa.numElements = M.numElements;
+    sa.numPackets = num_packets;
+    for (uint32_t e = 0; e < M.numElements; e++) {
+        const alac_hip_format ef = element_format(fmt, M.el[e].channels);
+        launch_mc_gather((const uint8_t *)d_pcm, ws + M.gather, d_num_samples, num_packets, fmt->frame_size,
+                         fmt->num_channels, M.el[e].first, M.el[e].channels, bytes_per_sample(fmt->bit_depth), ctx->stream);
+        // coefficient rows: [element][segment][64]
+        int16_t *st = d_state ? d_state + (uint64_t)e * num_segments * ALAC_HIP_STATE_INT16 : nullptr;
+        const int32_t rc = encode_core(ctx, &ef, ws + M.gather, d_num_samples, num_packets, d_seg_first, num_segments, st,
+                                       state_in, ws + M.sub, M.subBytes, ws + M.out[e], M.outCap[e],
+                                       (uint32_t *)(ws + M.sizes[e]), (uint64_t *)(ws + M.offs[e]), false);
+        if (rc != ALAC_HIP_noErr) return rc;
+        sa.el[e] = M.el[e];
+        sa.src[e] = ws + M.out[e];
+        sa.srcOffsets[e] = (const uint64_t *)(ws + M.offs[e]);
+    }
+    sa.elemBits = (uint32_t *)(ws + M.elemBits);
+    sa.packetBytes = d_packet_bytes;
+    sa.offsets = d_packet_offsets;
+    sa.out = d_out;
+    launch_mc_splice(sa, ctx->stream);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "splice launch", e);
+    return ALAC_HIP_noErr;
+}
+
+static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                           const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
+                           uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
+                           uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
+                           uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, bool timed)
+{
     if (num_packets == 0) return ALAC_HIP_noErr;
     if (!d_pcm || !d_workspace || !d_out || !d_packet_bytes || !d_packet_offsets)
         return fail(ctx, ALAC_HIP_ParamError, "null buffer");
@@ -297,7 +427,8 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
     pa.out = d_out;
     constexpr uint32_t EV = (kMaxSubBatches + 1) * (kNumStages + 1);
     hipEvent_t *ev = nullptr;
-    if (ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size()) ev = &ctx->events[ctx->profCalls++ * EV];
+    if (timed && ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size())
+        ev = &ctx->events[ctx->profCalls++ * EV];
     hipError_t e;
     if (use_lane_encoder()) {
         if (ev) ctx->profSub.push_back(0);
@@ -435,6 +566,34 @@ uint32_t alac_hip_magic_cookie(const alac_hip_format *fmt, uint32_t max_frame_by
     return 24;
 }
 
+uint32_t alac_hip_magic_cookie_size(const alac_hip_format *fmt)
+{
+    if (!format_ok(fmt)) return 0;
+    return fmt->num_channels > 2 ? 48 : 24;  // + kChannelAtomSize 12 + sizeof(ALACAudioChannelLayout) 12
+}
+
+uint32_t alac_hip_magic_cookie_full(const alac_hip_format *fmt, uint32_t max_frame_bytes, uint32_t avg_bit_rate,
+                                    uint8_t *c, uint32_t capacity)
+{
+    const uint32_t need = alac_hip_magic_cookie_size(fmt);
+    if (!need || !c || capacity < need) return 0;  // "no incomplete cookies", codec/ALACEncoder.cu:1136-1139
+    alac_hip_magic_cookie(fmt, max_frame_bytes, avg_bit_rate, c);
+    if (need == 24) return 24;
+    // ALACChannelLayoutTags, codec/ALACAudioTypes.h:103-124
+    static const uint32_t tags[kMaxChannels] = {(100u << 16) | 1, (101u << 16) | 2, (113u << 16) | 3, (116u << 16) | 4,
+                                                (120u << 16) | 5, (124u << 16) | 6, (142u << 16) | 7, (127u << 16) | 8};
+    memset(c + 24, 0, 24);
+    c[27] = 24;  // theChannelAtom[3] = sizeof(ALACAudioChannelLayout) + kChannelAtomSize
+    memcpy(c + 28, "chan", 4);
+    // the fork stores mChannelLayoutTag in host byte order (:1120 has no Swap32NtoB): little endian
+    const uint32_t t = tags[fmt->num_channels - 1];
+    c[36] = (uint8_t)t;
+    c[37] = (uint8_t)(t >> 8);
+    c[38] = (uint8_t)(t >> 16);
+    c[39] = (uint8_t)(t >> 24);
+    return 48;
+}
+
 int32_t alac_hip_format_from_cookie(const uint8_t *ck, uint32_t size, alac_hip_format *out)
 {
     if (!ck || !out) return ALAC_HIP_ParamError;
@@ -496,12 +655,15 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.pb = ck[6];
     da.mb = ck[7];
     da.kb = ck[8];
+    da.maxElems = L.maxElems;
     da.recs = (DecRec *)(ws + L.recs);
     da.resid = (int32_t *)(ws + L.resid);
     da.pcmOut = d_pcm_out;
     da.numSamplesOut = d_num_samples_out;
     da.statusOut = d_status;
-    hipError_t e = use_lane_decoder()
+    // element sequences (> 2 channels) run on the lane decoder: the position of element k + 1 is only known once
+    // element k is entropy-decoded
+    hipError_t e = (use_lane_decoder() || fmt.num_channels > 2)
                        ? launch_decode(da, ctx->stream)
                        : launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "decode launch", e);
@@ -583,6 +745,7 @@ int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *
 
     const uint32_t bpf = fmt->num_channels * bytes_per_sample(fmt->bit_depth);
     const uint32_t np = num_packets, nseg = num_segments;
+    const uint64_t stateBytes = (uint64_t)nseg * alac_hip_state_int16(fmt) * 2;
     const uint64_t pcmBytes = (uint64_t)np * fmt->frame_size * bpf;
     const uint64_t wsBytes = alac_hip_encode_workspace_bytes(fmt, np, nseg);
     const uint64_t outMax = alac_hip_encode_max_output_bytes(fmt, np);
@@ -590,7 +753,7 @@ int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *
     DevBuf dPcm, dNs, dSeg, dState, dWs, dOut, dSizes, dOffs;
     hipError_t e;
     if ((e = dPcm.alloc(pcmBytes)) || (e = dNs.alloc(np * 4ull)) || (e = dSeg.alloc((nseg + 1) * 4ull)) ||
-        (e = dState.alloc(nseg * 128ull)) || (e = dWs.alloc(wsBytes)) || (e = dOut.alloc(outMax)) ||
+        (e = dState.alloc(stateBytes)) || (e = dWs.alloc(wsBytes)) || (e = dOut.alloc(outMax)) ||
         (e = dSizes.alloc(np * 4ull)) || (e = dOffs.alloc((np + 1) * 8ull)))
         return fail(ctx, ALAC_HIP_MemFullError, "hipMalloc", e);
     hipStream_t st = ctx->stream;
@@ -599,7 +762,7 @@ int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *
         (e = hipMemcpyAsync(dSeg.p, h_seg_first, (nseg + 1) * 4ull, hipMemcpyHostToDevice, st)))
         return fail(ctx, ALAC_HIP_ParamError, "H2D copy", e);
     if (h_state && state_in)
-        if ((e = hipMemcpyAsync(dState.p, h_state, nseg * 128ull, hipMemcpyHostToDevice, st)))
+        if ((e = hipMemcpyAsync(dState.p, h_state, stateBytes, hipMemcpyHostToDevice, st)))
             return fail(ctx, ALAC_HIP_ParamError, "H2D state", e);
     int32_t rc = alac_hip_encode(ctx, fmt, dPcm.p, (const uint32_t *)dNs.p, np, (const uint32_t *)dSeg.p, nseg,
                                  (int16_t *)dState.p, (h_state && state_in) ? 1 : 0, dWs.p, wsBytes,
@@ -614,7 +777,7 @@ int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *
         (e = hipMemcpyAsync(h_packet_bytes, dSizes.p, np * 4ull, hipMemcpyDeviceToHost, st)))
         return fail(ctx, ALAC_HIP_ParamError, "D2H copy", e);
     if (h_state)
-        if ((e = hipMemcpyAsync(h_state, dState.p, nseg * 128ull, hipMemcpyDeviceToHost, st)))
+        if ((e = hipMemcpyAsync(h_state, dState.p, stateBytes, hipMemcpyDeviceToHost, st)))
             return fail(ctx, ALAC_HIP_ParamError, "D2H state", e);
     if ((e = hipStreamSynchronize(st))) return fail(ctx, ALAC_HIP_ParamError, "sync", e);
     if (out_total_bytes) *out_total_bytes = total;

@@ -114,21 +114,27 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
     const uint64_t off = A.offsets[p];
     const uint64_t nbytes = A.offsets[p + 1] - off;
     const uint8_t *base = A.stream + off;
-    DecRec *rec = A.recs + p;
     const uint64_t rs = A.numPackets;  // residual stride between consecutive samples
-    int32_t *resU = A.resid + p;
-    int32_t *resV = A.resid + (uint64_t)A.frameSize * rs + p;
+    // one record per element (codec/ALACDecoder.cu:600-990 loops over the elements of a packet until every channel
+    // of the cookie is decoded or ID_END is met); record 0 also carries the packet's status
+    uint32_t elem = 0, channelIndex = 0;
+    for (uint32_t e = 0; e < A.maxElems; e++) {
+        DecRec *r = A.recs + (uint64_t)e * A.numPackets + p;
+        r->numSamples = 0;
+        r->escape = 0;
+        r->mixBits = r->mixRes = 0;
+        r->bytesShifted = 0;
+        r->elementChannels = 0;
+        r->shiftPos = 0;
+        r->chanIndex = 0;
+    }
+    DecRec *rec = A.recs + p;
+    uint32_t lastSamples = 0;
 
     uint64_t pos = 0;
     uint32_t numSamples = A.frameSize;
     int32_t status = 0;
     bool done = false;
-    rec->numSamples = 0;
-    rec->escape = 0;
-    rec->mixBits = rec->mixRes = 0;
-    rec->bytesShifted = 0;
-    rec->elementChannels = 0;
-    rec->shiftPos = 0;
 
     while (!done && status == 0) {
         if (!((pos >> 3) < nbytes)) {  // :615
@@ -141,10 +147,13 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
         case 3:    // ID_LFE
         case 1: {  // ID_CPE
             const uint32_t ech = (tag == 1) ? 2u : 1u;
-            if (ech != A.numChannels) {  // > 2-channel layouts (several elements) are not built yet
-                status = -4;
+            if (channelIndex + ech > A.numChannels) {  // :760-762 (a pair that does not fit ends the packet)
+                done = true;
                 break;
             }
+            rec = A.recs + (uint64_t)elem * A.numPackets + p;
+            int32_t *resU = A.resid + (uint64_t)channelIndex * A.frameSize * rs + p;
+            int32_t *resV = resU + (uint64_t)A.frameSize * rs;
             (void)read_bits(base, nbytes, pos, 4);
             if (read_bits(base, nbytes, pos, 12) != 0) {  // :633 / :768
                 status = -50;
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
                 break;
             }
             rec->elementChannels = ech;
+            rec->chanIndex = channelIndex;
             if (!esc) {
                 const uint32_t mixBits = read_bits(base, nbytes, pos, 8);
                 const int32_t mixRes = (int8_t)read_bits(base, nbytes, pos, 8);
@@ -198,7 +208,10 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
                 rec->escape = 1;
             }
             rec->numSamples = numSamples;
-            done = true;  // channelIndex >= numChannels, :967
+            lastSamples = numSamples;
+            channelIndex += ech;
+            elem++;
+            done = channelIndex >= A.numChannels;  // :967
             break;
         }
         case 2:  // ID_CCE
@@ -227,9 +240,20 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
             break;
         }
     }
-    rec->status = status;
+    A.recs[p].status = status;
     A.statusOut[p] = status;
-    A.numSamplesOut[p] = status == 0 ? rec->numSamples : 0;
+    A.numSamplesOut[p] = status == 0 ? lastSamples : 0;
+}
+
+// the element record that carries output channel ch of packet p (nullptr: the packet has none for it)
+__device__ __forceinline__ const DecRec *element_of(const DecodeArgs &A, uint32_t p, uint32_t ch)
+{
+    for (uint32_t e = 0; e < A.maxElems; e++) {
+        const DecRec *r = A.recs + (uint64_t)e * A.numPackets + p;
+        if (r->elementChannels == 0) break;
+        if (ch >= r->chanIndex && ch < r->chanIndex + r->elementChannels) return r;
+    }
+    return nullptr;
 }
 
 __global__ __launch_bounds__(64) void k_decode_unpc(DecodeArgs A)
@@ -238,11 +262,12 @@ __global__ __launch_bounds__(64) void k_decode_unpc(DecodeArgs A)
     if (gid >= (uint64_t)A.numPackets * A.numChannels) return;
     const uint32_t ch = (uint32_t)(gid / A.numPackets);
     const uint32_t p = (uint32_t)(gid % A.numPackets);
-    const DecRec *rec = A.recs + p;
-    if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return;
+    if (A.recs[p].status != 0) return;
+    const DecRec *rec = element_of(A, p, ch);
+    if (!rec || rec->escape) return;
     const uint32_t chanbits = A.bitDepth - rec->bytesShifted * 8 + (rec->elementChannels == 2 ? 1 : 0);
     int32_t *row = A.resid + (uint64_t)ch * A.frameSize * A.numPackets + p;
-    const DecChan &c = rec->c[ch];
+    const DecChan &c = rec->c[ch - rec->chanIndex];
     // :829-838: mode != 0 runs the first-order pass first
     if (c.mode != 0) unpc_first_order(row, A.numPackets, rec->numSamples, 32 - chanbits);
     unpc_any(row, A.numPackets, rec->numSamples, c.coefs, c.num, chanbits, c.denShift);
@@ -321,11 +346,74 @@ __global__ __launch_bounds__(256) void k_decode_unmix(DecodeArgs A)
     }
 }
 
+// > 2 channels: the same tile walk once per output channel c; a packet's element that STARTS at c is un-mixed and
+// written at channel c (and c + 1) of the numChannels-interleaved frame (unmixNN / copyPredictorToNN with stride
+// numChannels, codec/ALACDecoder.cu:733-753,:900-935); channels no element carries are zero (:971-998).
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_decode_unmix_mc(DecodeArgs A)
+{
+    __shared__ int32_t tu[64][65];
+    __shared__ int32_t tv[64][65];
+    const uint32_t tileP = blockIdx.x * 64u, tileJ = blockIdx.y * 64u;
+    const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    constexpr uint32_t BPS = bytes_per_sample(DEPTH);
+    const uint32_t nch = A.numChannels;
+    for (uint32_t c = 0; c < nch; c++) {
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t jj = grp + 4 * i;
+            const uint32_t j = tileJ + jj, p = tileP + lane;
+            int32_t u = 0, v = 0;
+            if (p < A.numPackets && j < A.frameSize) {
+                u = A.resid[((uint64_t)c * A.frameSize + j) * A.numPackets + p];
+                if (c + 1 < nch) v = A.resid[((uint64_t)(c + 1) * A.frameSize + j) * A.numPackets + p];
+            }
+            tu[jj][lane] = u;
+            tv[jj][lane] = v;
+        }
+        __syncthreads();
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t pp = grp + 4 * i;
+            const uint32_t p = tileP + pp, j = tileJ + lane;
+            if (p >= A.numPackets || A.recs[p].status != 0) continue;
+            const DecRec *rec = element_of(A, p, c);
+            uint8_t *op = A.pcmOut + (((uint64_t)p * A.frameSize + j) * nch + c) * BPS;
+            if (!rec) {
+                const uint32_t ns = A.recs[p].elementChannels ? A.recs[p].numSamples : A.frameSize;
+                if (j < ns) store_sample<DEPTH>(op, 0);
+                continue;
+            }
+            if (rec->chanIndex != c || j >= rec->numSamples) continue;
+            const uint32_t shb = rec->bytesShifted, ech = rec->elementChannels;
+            int32_t l, r = 0;
+            const int32_t u = tu[lane][pp], v = tv[lane][pp];
+            if (ech == 2 && rec->mixRes != 0) {
+                l = u + v - ((rec->mixRes * v) >> rec->mixBits);
+                r = l - v;
+            } else {
+                l = u;
+                r = v;
+            }
+            if (shb != 0 && DEPTH >= 24) {
+                const uint8_t *base = A.stream + A.offsets[p];
+                const uint64_t nbytes = A.offsets[p + 1] - A.offsets[p];
+                uint64_t sp = rec->shiftPos + (uint64_t)j * ech * shb * 8;
+                l = (int32_t)(((uint32_t)l << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
+                if (ech == 2) r = (int32_t)(((uint32_t)r << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
+            }
+            store_sample<DEPTH>(op, l);
+            if (ech == 2) store_sample<DEPTH>(op + BPS, r);
+        }
+        __syncthreads();
+    }
+}
+
 template <int DEPTH>
 static void launch_unmix_depth(const DecodeArgs &da, hipStream_t st)
 {
     dim3 grid((da.numPackets + 63) / 64, (da.frameSize + 63) / 64);
-    if (da.numChannels == 2)
+    if (da.numChannels > 2)
+        hipLaunchKernelGGL((k_decode_unmix_mc<DEPTH>), grid, dim3(256), 0, st, da);
+    else if (da.numChannels == 2)
         hipLaunchKernelGGL((k_decode_unmix<DEPTH, 2>), grid, dim3(256), 0, st, da);
     else
         hipLaunchKernelGGL((k_decode_unmix<DEPTH, 1>), grid, dim3(256), 0, st, da);

@@ -679,6 +679,11 @@ static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, con
     if (ev) (void)hipEventRecord(ev[kNumStages], st);
 }
 
+void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, sizes, offsets, n);
+}
+
 void launch_scan_pack(uint32_t depth, uint32_t channels, uint32_t *packetBytes, const PackArgs &pa, uint32_t numPackets,
                       hipStream_t st, hipEvent_t *ev, bool recordScan)
 {

@@ -107,8 +107,10 @@ struct DecRec {
     uint32_t bytesShifted;
     uint32_t elementChannels;  // 1 (SCE/LFE) or 2 (CPE)
     uint64_t shiftPos;         // bit position of the shift-off section inside the packet
-    int32_t status;
-    uint32_t pad;
+    int32_t status;            // of the whole packet in element record 0
+    uint32_t pad;              // second-generation decoder: first payload bit of the element
+    uint32_t chanIndex;        // first output channel of this element (lane decoder, element sequences)
+    uint32_t pad2;
     DecChan c[2];
 };
 
@@ -118,7 +120,8 @@ struct DecodeArgs {
     uint32_t numPackets;
     uint32_t frameSize, bitDepth, numChannels;
     uint32_t mb, pb, kb;
-    DecRec *recs;
+    uint32_t maxElems;  // element records per packet: 1 for <= 2 channels, numChannels above (lane decoder only)
+    DecRec *recs;       // [maxElems][numPackets]
     int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
     uint8_t *pcmOut;
     uint32_t *numSamplesOut;
@@ -130,6 +133,33 @@ hipError_t launch_decode(const DecodeArgs &da, hipStream_t st);
 // numPackets * numChannels * frameSize int32, `prog` = 2 * numPackets uint32 (progress words of the fused launch)
 hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
                             hipStream_t st);
+
+// ---- > 2 channels (alac_multichannel.hip): a packet is a sequence of mono / stereo elements ----
+struct McElement {
+    uint32_t first;     // channel index of the element's first channel
+    uint32_t channels;  // 1 (ID_SCE) or 2 (ID_CPE)
+    uint32_t tag;       // element type (3 bits) << 4 | instance tag (4 bits)
+};
+constexpr uint32_t kMaxChannels = 8;
+// the element sequence of a channel count (sChannelMaps, codec/ALACEncoder.cu:97-107); returns the count
+uint32_t channel_elements(uint32_t numChannels, McElement *out);
+struct McSpliceArgs {
+    uint32_t numElements, numPackets;
+    McElement el[kMaxChannels];
+    const uint8_t *src[kMaxChannels];          // one-element packets of every element, back to back
+    const uint64_t *srcOffsets[kMaxChannels];  // [numPackets + 1]
+    uint32_t *elemBits;                        // [numElements][numPackets] scratch
+    uint32_t *packetBytes;
+    uint64_t *offsets;
+    uint8_t *out;
+};
+// channels [first, first + channels) of an interleaved stream -> a compact mono / stereo stream (valid frames only)
+void launch_mc_gather(const uint8_t *pcm, uint8_t *out, const uint32_t *numSamples, uint32_t numPackets,
+                      uint32_t frameSize, uint32_t numChannels, uint32_t first, uint32_t channels, uint32_t bytesPerSample,
+                      hipStream_t st);
+// sizes + exclusive scan + bit-granular concatenation of the element packets
+void launch_mc_splice(const McSpliceArgs &a, hipStream_t st);
+void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st);
 
 // ---- stage-level ----
 hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,

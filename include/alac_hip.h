@@ -25,9 +25,12 @@ enum {
     ALAC_HIP_MemFullError = -108
 };
 
-/* Number of int16 values of persistent encoder state per segment: the predictor rows the search
- * touches, [U row 3][U row 7][V row 3][V row 7] x 16 coefficients — the live subset of
- * ALACEncoder::mCoefsU/V (codec/ALACEncoder.h:89-90, rows numUV-1 of codec/ALACEncoder.cu:361,429). */
+/* Number of int16 values of persistent encoder state per segment and element: the predictor rows the
+ * search touches, [U row 3][U row 7][V row 3][V row 7] x 16 coefficients — the live subset of
+ * ALACEncoder::mCoefsU/V (codec/ALACEncoder.h:89-90, rows numUV-1 of codec/ALACEncoder.cu:361,429).
+ * Mono and stereo streams have one element; a stream of 3..8 channels has one block per element of its
+ * packets (mCoefsU/V[channelIndex] of the element's first channel), laid out [element][segment][64]:
+ * alac_hip_state_int16(fmt) = 64 x elements is the per-segment total. */
 #define ALAC_HIP_STATE_INT16 64
 
 typedef struct alac_hip_ctx alac_hip_ctx;
@@ -37,9 +40,13 @@ typedef struct alac_hip_ctx alac_hip_ctx;
 typedef struct alac_hip_format {
     uint32_t frame_size;   /* sample-frames per packet; kALACDefaultFramesPerPacket = 4096 */
     uint32_t bit_depth;    /* 16, 20, 24 or 32 (mFormatFlags 1..4) */
-    uint32_t num_channels; /* 1 (ID_SCE) or 2 (ID_CPE) */
+    uint32_t num_channels; /* 1 (ID_SCE), 2 (ID_CPE) or 3..8: the element sequence of sChannelMaps
+                            * (codec/ALACEncoder.cu:97-107), e.g. 6 = SCE CPE CPE SCE */
     uint32_t sample_rate;  /* only carried into the magic cookie */
 } alac_hip_format;
+
+/* int16 values of coefficient state per segment for this format (64 x elements per packet). */
+uint32_t alac_hip_state_int16(const alac_hip_format *fmt);
 
 /* ---- context ---------------------------------------------------------------------------- */
 
@@ -78,8 +85,9 @@ uint64_t alac_hip_encode_max_output_bytes(const alac_hip_format *fmt, uint32_t n
  *   d_seg_first      [num_segments + 1] first packet index of each segment (a segment = a run of
  *                    packets chained through the coefficient state), or NULL =
  *                    every packet is its own segment (state = init_coefs, codec/dp_enc.c:49-60)
- *   d_state          [num_segments][ALAC_HIP_STATE_INT16] coefficient rows; read as the initial
- *                    state when state_in != 0, always written with the final state when non-NULL
+ *   d_state          [elements][num_segments][ALAC_HIP_STATE_INT16] coefficient rows (elements = 1 up
+ *                    to 2 channels); read as the initial state when state_in != 0, always written
+ *                    with the final state when non-NULL
  *   d_out            packets written back to back (each byte-aligned, codec/ALACEncoder.cu:1039)
  *   d_packet_bytes   [num_packets] size of each packet (the *ioNumBytes of Encode)
  *   d_packet_offsets [num_packets + 1] exclusive scan of the sizes; last entry = total bytes
@@ -109,6 +117,13 @@ const char *alac_hip_stage_name(uint32_t stage);
  * (codec/ALACEncoder.cu:1082-1140) for <= 2 channels.  Host-only, no device work. */
 uint32_t alac_hip_magic_cookie(const alac_hip_format *fmt, uint32_t max_frame_bytes,
                                uint32_t avg_bit_rate, uint8_t *h_cookie24);
+/* GetMagicCookieSize / GetMagicCookie for any channel count (codec/ALACEncoder.cu:1097-1140): above 2
+ * channels the config is followed by the 12-byte 'chan' atom header and the 12-byte
+ * ALACAudioChannelLayout (48 bytes in all; the layout tag in host byte order as the fork writes it).
+ * Returns the bytes written, 0 if `capacity` is too small ("no incomplete cookies", :1136-1139). */
+uint32_t alac_hip_magic_cookie_size(const alac_hip_format *fmt);
+uint32_t alac_hip_magic_cookie_full(const alac_hip_format *fmt, uint32_t max_frame_bytes,
+                                    uint32_t avg_bit_rate, uint8_t *h_cookie, uint32_t capacity);
 
 /* ---- batch decode: replaces ALACDecoder::Decode + fillWriteBuffer ---------------------------
  * (codec/ALACDecoder.cu:571-1002, :497-563; dyn_decomp codec/ag_dec.c:272, unpc_block

@@ -1,0 +1,96 @@
+"""GPU parity for streams of 3..8 channels: the element sequence of sChannelMaps through the
+C-ABI, bit-exact against the CPU oracle's element loop; decode through the lane decoder's element loop."""
+import numpy as np
+import pytest
+
+import alac_amd
+from oracle_lib import channel_elements, interleave_channels
+
+pytestmark = pytest.mark.gpu
+
+
+def _pcm(oracle, channels, depth, first, packets):
+    parts = []
+    for k, (ci, n) in enumerate(channel_elements(oracle, channels)):
+        parts.append((alac_amd.synth_pcm(first + 16 * k, packets, alac_amd.make_format(4096, depth, n)), n))
+    return interleave_channels(parts, depth)
+
+
+@pytest.mark.parametrize("channels,depth", [(3, 16), (4, 24), (5, 16), (6, 16), (6, 24), (7, 20), (8, 16), (8, 32)])
+def test_independent_packets_and_round_trip(gpu_ctx, oracle, channels, depth):
+    import torch
+    fmt = alac_amd.make_format(4096, depth, channels)
+    n = 20
+    sizes_in = [4096] * n
+    sizes_in[3], sizes_in[7], sizes_in[19] = 1000, 5, 404
+    pcm = _pcm(oracle, channels, depth, 0, n)
+    ns = torch.tensor(sizes_in, dtype=torch.int32).cuda()
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, num_samples=ns)
+    enc = oracle.encoder(4096, depth, channels)
+    off = 0
+    for p, N in enumerate(sizes_in):
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + N * fmt.bytes_per_frame], N)
+        assert sizes[p] == len(pk), (p, N)
+        assert np.array_equal(stream[off:off + len(pk)], pk), (p, N)
+        off += len(pk)
+    assert off == len(stream)
+    cookie = gpu_ctx.magic_cookie(fmt)
+    assert np.array_equal(cookie, oracle.encoder(4096, depth, channels).cookie())  # fetched before encoding
+    offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    out, nso, st, f2 = gpu_ctx.decode(cookie, torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), n)
+    gpu_ctx.synchronize()
+    assert f2.num_channels == channels and not st.cpu().numpy().any()
+    assert np.array_equal(nso.cpu().numpy(), np.array(sizes_in))
+    out = out.cpu().numpy()
+    for p, N in enumerate(sizes_in):
+        a = p * fmt.packet_bytes
+        assert np.array_equal(out[a:a + N * fmt.bytes_per_frame], pcm[a:a + N * fmt.bytes_per_frame]), p
+
+
+@pytest.mark.parametrize("channels,depth", [(6, 16), (3, 24)])
+def test_chained_segments(gpu_ctx, oracle, channels, depth):
+    """every element keeps its own coefficient rows across the packets of a segment; the state blocks are laid out
+    [element][segment][64] and continue a chain in a second call"""
+    import torch
+    fmt = alac_amd.make_format(4096, depth, channels)
+    seg_first = [0, 3, 4, 9]
+    nseg, n = len(seg_first) - 1, seg_first[-1]
+    nel = len(channel_elements(oracle, channels))
+    assert gpu_ctx.lib.alac_hip_state_int16(fmt) == 64 * nel
+    pcm = _pcm(oracle, channels, depth, 7, n)
+    sf = torch.tensor(seg_first, dtype=torch.int32).cuda()
+    state = torch.zeros((nel, nseg, 64), dtype=torch.int16).cuda()
+    half = [0, 2, 3, 6]  # first call: the first packets of every segment; second call: the rest, from the state
+    idx1 = [p for s in range(nseg) for p in range(seg_first[s], seg_first[s] + half[s + 1] - half[s])]
+    idx2 = [p for p in range(n) if p not in idx1]
+
+    def take(idx):
+        return np.concatenate([pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes] for p in idx])
+
+    s1, z1 = gpu_ctx.encode_to_host(fmt, torch.from_numpy(take(idx1)).cuda(), len(idx1),
+                                    seg_first=torch.tensor(half, dtype=torch.int32).cuda(), state=state)
+    rest = [0]
+    for s in range(nseg):
+        rest.append(rest[-1] + (seg_first[s + 1] - seg_first[s]) - (half[s + 1] - half[s]))
+    s2, z2 = gpu_ctx.encode_to_host(fmt, torch.from_numpy(take(idx2)).cuda(), len(idx2),
+                                    seg_first=torch.tensor(rest, dtype=torch.int32).cuda(), state=state, state_in=True)
+    whole, zw = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, seg_first=sf)
+    got = {}
+    o = 0
+    for k, p in enumerate(idx1):
+        got[p] = s1[o:o + int(z1[k])]
+        o += int(z1[k])
+    o = 0
+    for k, p in enumerate(idx2):
+        got[p] = s2[o:o + int(z2[k])]
+        o += int(z2[k])
+    off = 0
+    for s in range(nseg):
+        a, b = seg_first[s], seg_first[s + 1]
+        ref, rs = oracle.encoder(4096, depth, channels).encode_stream(pcm[a * fmt.packet_bytes:b * fmt.packet_bytes],
+                                                                      (b - a) * 4096, 0)
+        assert np.array_equal(zw[a:b], rs)
+        assert np.array_equal(whole[off:off + len(ref)], ref), s
+        assert np.array_equal(np.concatenate([got[p] for p in range(a, b)]), ref), s
+        off += len(ref)
