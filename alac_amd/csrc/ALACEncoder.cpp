@@ -42,7 +42,7 @@ int32_t ALACEncoder::InitializeEncoder(AudioFormatDescription theOutputFormat, i
     default: break;
     }
     if (!(mBitDepth == 16 || mBitDepth == 20 || mBitDepth == 24 || mBitDepth == 32)) return kALAC_ParamError;
-    if (mNumChannels < 1 || mNumChannels > 2) return kALAC_UnimplementedError;  // > 2 ch: SURVEY §8f-3
+    if (mNumChannels < 1 || mNumChannels > kALACMaxChannels) return kALAC_ParamError;
     mMaxOutputBytes = mFrameSize * mNumChannels * ((10 + 32) / 8) + 1;        // :1489
     if (!mCtx) {
         const char *dev = getenv("ALAC_HIP_DEVICE");
@@ -72,17 +72,27 @@ void ALACEncoder::GetConfig(ALACSpecificConfig &config)
     config.sampleRate = be32(mOutputSampleRate);
 }
 
-// :1097-1107 (the > 2-channel layout atom is not produced: multichannel is not built yet)
-uint32_t ALACEncoder::GetMagicCookieSize(uint32_t /*inNumChannels*/) { return sizeof(ALACSpecificConfig); }
+// :1097-1107
+uint32_t ALACEncoder::GetMagicCookieSize(uint32_t inNumChannels)
+{
+    return inNumChannels > 2 ? (uint32_t)sizeof(ALACSpecificConfig) + 24u : (uint32_t)sizeof(ALACSpecificConfig);
+}
 
 // :1109-1140
 void ALACEncoder::GetMagicCookie(void *outCookie, uint32_t *ioSize)
 {
     ALACSpecificConfig cfg;
     GetConfig(cfg);
-    if (*ioSize >= sizeof(cfg)) {
+    const uint32_t need = GetMagicCookieSize(mNumChannels);
+    if (*ioSize >= need) {
         memcpy(outCookie, &cfg, sizeof(cfg));
-        *ioSize = sizeof(cfg);
+        if (need > sizeof(cfg)) {  // 'chan' atom + ALACAudioChannelLayout (:1118-1133)
+            uint8_t full[48];
+            alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
+            alac_hip_magic_cookie_full(&fmt, mMaxFrameBytes, mAvgBitRate, full, sizeof(full));
+            memcpy((uint8_t *)outCookie + sizeof(cfg), full + 24, 24);
+        }
+        *ioSize = need;
     } else {
         *ioSize = 0;  // no incomplete cookies
     }
@@ -102,15 +112,16 @@ int32_t ALACEncoder::EncodeBatch(const void *pcm, uint64_t totalSamples, uint32_
     alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
     const uint64_t np = (totalSamples + mFrameSize - 1) / mFrameSize;
     const uint64_t nseg = segmentPackets ? (np + segmentPackets - 1) / segmentPackets : 1;
-    std::vector<int16_t> state(nseg * 64, 0);
+    const uint32_t stateInt16 = alac_hip_state_int16(&fmt);  // 64 per element of a packet
+    std::vector<int16_t> state(nseg * stateInt16, 0);
     const bool chain = (segmentPackets == 0) && mStateValid;
-    if (chain) memcpy(state.data(), mState, sizeof(mState));
+    if (chain) memcpy(state.data(), mState, stateInt16 * 2u);
     uint64_t total = 0;
     mLastStatus = alac_hip_encode_host(mCtx, &fmt, pcm, totalSamples, segmentPackets, state.data(), chain ? 1 : 0, out,
                                        outCapacity, packetBytes, &total);
     if (mLastStatus != ALAC_HIP_noErr) return mLastStatus;
     if (segmentPackets == 0 && np) {
-        memcpy(mState, state.data(), sizeof(mState));
+        memcpy(mState, state.data(), stateInt16 * 2u);
         mStateValid = true;
     }
     for (uint64_t p = 0; p < np; p++) account(packetBytes[p]);
@@ -155,19 +166,20 @@ void ALACEncoder::InitializeSampling(void *d_ip, AudioFormatDescription theInput
     if (np == 0) return;
     alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
     const uint32_t segFirst[2] = {0, np};
+    const uint64_t stateBytes = alac_hip_state_int16(&fmt) * 2ull;
     const uint64_t wsBytes = alac_hip_encode_workspace_bytes(&fmt, np, 1);
     const uint64_t outMax = alac_hip_encode_max_output_bytes(&fmt, np);
     void *dNs = nullptr, *dSeg = nullptr, *dState = nullptr, *dWs = nullptr, *dOut = nullptr, *dSizes = nullptr,
          *dOffs = nullptr;
     hipStream_t st = (hipStream_t)alac_hip_stream(mCtx);
     bool ok = hipMalloc(&dNs, np * 4ull) == hipSuccess && hipMalloc(&dSeg, 8) == hipSuccess &&
-              hipMalloc(&dState, 128) == hipSuccess && hipMalloc(&dWs, wsBytes) == hipSuccess &&
+              hipMalloc(&dState, stateBytes) == hipSuccess && hipMalloc(&dWs, wsBytes) == hipSuccess &&
               hipMalloc(&dOut, outMax) == hipSuccess && hipMalloc(&dSizes, np * 4ull) == hipSuccess &&
               hipMalloc(&dOffs, (np + 1) * 8ull) == hipSuccess;
     if (ok) {
         ok = hipMemcpyAsync(dNs, ns.data(), np * 4ull, hipMemcpyHostToDevice, st) == hipSuccess &&
              hipMemcpyAsync(dSeg, segFirst, 8, hipMemcpyHostToDevice, st) == hipSuccess;
-        if (ok && mStateValid) ok = hipMemcpyAsync(dState, mState, 128, hipMemcpyHostToDevice, st) == hipSuccess;
+        if (ok && mStateValid) ok = hipMemcpyAsync(dState, mState, stateBytes, hipMemcpyHostToDevice, st) == hipSuccess;
     }
     if (ok) {
         mLastStatus = alac_hip_encode(mCtx, &fmt, d_ip, (const uint32_t *)dNs, np, (const uint32_t *)dSeg, 1,
@@ -182,7 +194,7 @@ void ALACEncoder::InitializeSampling(void *d_ip, AudioFormatDescription theInput
         mBatchOffsets.resize(np + 1);
         ok = hipMemcpyAsync(mBatchSizes.data(), dSizes, np * 4ull, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipMemcpyAsync(mBatchOffsets.data(), dOffs, (np + 1) * 8ull, hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipMemcpyAsync(mState, dState, 128, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipMemcpyAsync(mState, dState, stateBytes, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
         if (ok) {
             mBatchStream.resize(mBatchOffsets[np]);

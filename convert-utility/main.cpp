@@ -259,7 +259,7 @@ int main(int argc, char *argv[])
                 fprintf(stderr, " 20-bit PCM files are not supported by the convert utility: \"%s\"\n", J.in.c_str());
                 return 1;
             }
-            if ((b != 16 && b != 24 && b != 32) || J.info.channels < 1 || J.info.channels > 2) {
+            if ((b != 16 && b != 24 && b != 32) || J.info.channels < 1 || J.info.channels > 8) {  // kALACMaxChannels
                 fprintf(stderr, " File \"%s\'s\" data format is of an unsupported type\n", J.in.c_str());
                 return 1;
             }

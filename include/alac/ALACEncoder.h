@@ -62,7 +62,7 @@ protected:
 
 private:
     alac_hip_ctx *mCtx;
-    int16_t mState[64];  /* rows 3 and 7 of mCoefsU/V[0] (codec/ALACEncoder.h:89-90) */
+    int16_t mState[64 * 8]; /* rows 3 and 7 of mCoefsU/V[first channel of every element] (codec/ALACEncoder.h:89-90) */
     bool mStateValid;
     std::vector<uint8_t> mBatchStream;
     std::vector<uint32_t> mBatchSizes;

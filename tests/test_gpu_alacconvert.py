@@ -129,3 +129,29 @@ def test_bad_invocations(binary, tmp_path):
     junk.write_bytes(b"not a wave file at all")
     rc, _, err = run(binary, junk, tmp_path / "o.caf")
     assert rc == 1 and "Cannot determine what format" in err
+
+
+@pytest.mark.parametrize("bits,ch,frames", [(16, 6, 4096 * 2 + 300), (24, 3, 4096 + 11), (16, 8, 4096)])
+def test_multichannel_files(binary, oracle, tmp_path, bits, ch, frames):
+    """3..8 channels: 'chan' chunk after the 48-byte 'kuki', element packets; decode only to CAF
+    (convert-utility/main.cu:169-174 refuses WAVE above two channels)"""
+    pcm = music_like(frames, ch, bits, 30 + ch)
+    wav = co.make_wav(pcm, ch, 48000, bits)
+    src, caf, back = tmp_path / "in.wav", tmp_path / "out.caf", tmp_path / "back.caf"
+    src.write_bytes(wav)
+    rc, _, err = run(binary, src, caf)
+    assert rc == 0, err
+    cookie, enc, dec = oracle_codec(oracle, bits, ch, 48000)
+    assert len(cookie) == 48
+    want = co.encode_file(wav, cookie, enc)
+    assert caf.read_bytes() == want
+    rc, _, err = run(binary, caf, tmp_path / "back.wav")
+    assert rc == 1 and "more than two channels" in err
+    rc, _, err = run(binary, caf, back)
+    assert rc == 0, err
+    got = back.read_bytes()
+    assert got == co.decode_file(want, False, dec)
+    assert got.endswith(pcm)
+    again = tmp_path / "again.caf"
+    assert run(binary, back, again)[0] == 0
+    assert again.read_bytes() == want
