@@ -28,6 +28,10 @@ struct alac_hip_ctx {
     // side streams / events of the sub-batch overlap (created on first use)
     V1Streams vs{};
     bool vsReady = false;
+    // second stream of the > 2-channel encoder (mono elements beside the stereo ones)
+    hipStream_t mcStream = nullptr;
+    hipEvent_t mcFork = nullptr, mcJoin = nullptr;
+    bool mcReady = false;
 };
 
 namespace {
@@ -142,10 +146,17 @@ uint64_t max_output_bytes(const alac_hip_format *fmt, uint32_t num_packets)
     return align_up(per * num_packets + 8, 16);
 }
 
+// the elements of one type form one batch of count * numPackets one-element packets (sub-packet k * P + p)
+struct McGroup {
+    uint32_t channels, count, elem[kMaxChannels];
+    uint64_t gather, sub, subBytes, out, outCap, sizes, offs, ns, seg, state;
+};
+
 struct McLayout {
     uint32_t numElements;
     McElement el[kMaxChannels];
-    uint64_t gather, sub, subBytes, out[kMaxChannels], outCap[kMaxChannels], sizes[kMaxChannels], offs[kMaxChannels];
+    uint32_t groupOf[kMaxChannels], indexInGroup[kMaxChannels];
+    McGroup g[2];  // [0] stereo elements, [1] mono elements
     uint64_t elemBits, total;
 };
 
@@ -153,22 +164,38 @@ McLayout mc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t numSe
 {
     McLayout M;
     M.numElements = channel_elements(f->num_channels, M.el);
-    const alac_hip_format f1 = element_format(f, 1), f2 = element_format(f, 2);
-    uint64_t off = 0;
-    M.gather = off;
-    off = align_up(off + (uint64_t)numPackets * f->frame_size * 2 * bytes_per_sample(f->bit_depth) + 64, 256);
-    M.sub = off;
-    const uint64_t s1 = enc_layout(&f1, numPackets, numSegments).total, s2 = enc_layout(&f2, numPackets, numSegments).total;
-    M.subBytes = s1 > s2 ? s1 : s2;
-    off = align_up(off + M.subBytes, 256);
+    M.g[0].channels = 2;
+    M.g[1].channels = 1;
+    M.g[0].count = M.g[1].count = 0;
     for (uint32_t e = 0; e < M.numElements; e++) {
-        M.outCap[e] = max_output_bytes(M.el[e].channels == 2 ? &f2 : &f1, numPackets);
-        M.out[e] = off;
-        off = align_up(off + M.outCap[e] + 16, 256);
-        M.sizes[e] = off;
-        off = align_up(off + (uint64_t)numPackets * 4, 256);
-        M.offs[e] = off;
-        off = align_up(off + ((uint64_t)numPackets + 1) * 8, 256);
+        McGroup &G = M.g[M.el[e].channels == 2 ? 0 : 1];
+        M.groupOf[e] = M.el[e].channels == 2 ? 0 : 1;
+        M.indexInGroup[e] = G.count;
+        G.elem[G.count++] = e;
+    }
+    uint64_t off = 0;
+    for (int gi = 0; gi < 2; gi++) {
+        McGroup &G = M.g[gi];
+        const alac_hip_format gf = element_format(f, G.channels);
+        const uint64_t subPackets = (uint64_t)G.count * numPackets, subSegments = (uint64_t)G.count * numSegments;
+        G.gather = off;
+        off = align_up(off + subPackets * f->frame_size * G.channels * bytes_per_sample(f->bit_depth) + 64, 256);
+        G.sub = off;
+        G.subBytes = G.count ? enc_layout(&gf, (uint32_t)subPackets, (uint32_t)subSegments).total : 0;
+        off = align_up(off + G.subBytes, 256);
+        G.outCap = max_output_bytes(&gf, (uint32_t)subPackets);
+        G.out = off;
+        off = align_up(off + G.outCap + 16, 256);
+        G.sizes = off;
+        off = align_up(off + subPackets * 4, 256);
+        G.offs = off;
+        off = align_up(off + (subPackets + 1) * 8, 256);
+        G.ns = off;
+        off = align_up(off + subPackets * 4, 256);
+        G.seg = off;
+        off = align_up(off + (subSegments + 1) * 4, 256);
+        G.state = off;
+        off = align_up(off + subSegments * ALAC_HIP_STATE_INT16 * 2, 256);
     }
     M.elemBits = off;
     off = align_up(off + (uint64_t)M.numElements * numPackets * 4, 256);
@@ -270,6 +297,13 @@ void alac_hip_destroy(alac_hip_ctx *ctx)
         }
         (void)hipEventDestroy(ctx->vs.fork);
     }
+    if (ctx->mcReady) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->mcStream);
+        (void)hipStreamDestroy(ctx->mcStream);
+        (void)hipEventDestroy(ctx->mcFork);
+        (void)hipEventDestroy(ctx->mcJoin);
+    }
     if (ctx->ownStream && ctx->stream) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
@@ -350,34 +384,80 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
     if (!d_seg_first) num_segments = num_packets;
     if (num_segments == 0 || num_segments > num_packets) return fail(ctx, ALAC_HIP_ParamError, "bad segment count");
     if (((uintptr_t)d_workspace & 255)) return fail(ctx, ALAC_HIP_ParamError, "misaligned workspace (256 B)");
+    if ((uint64_t)num_packets * kMaxChannels > 0x7fffffffull) return fail(ctx, ALAC_HIP_ParamError, "too many packets");
     const McLayout M = mc_layout(fmt, num_packets, num_segments);
     if (workspace_bytes < M.total) return fail(ctx, ALAC_HIP_ParamError, "workspace too small");
     if (out_capacity < max_output_bytes(fmt, num_packets))
         return fail(ctx, ALAC_HIP_ParamError, "output capacity below alac_hip_encode_max_output_bytes");
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
     uint8_t *ws = (uint8_t *)d_workspace;
+    const uint32_t bps = bytes_per_sample(fmt->bit_depth);
+    hipStream_t mainStream = ctx->stream;
+
+    // the stereo batch runs on the context's stream, the mono batch beside it on a second stream (both are bound by
+    // the latency of one wave, not by the machine)
+    const bool both = M.g[0].count && M.g[1].count;
+    bool side = both && sub_batches_requested() == 1;
+    if (side && !ctx->mcReady) {
+        if (hipStreamCreateWithFlags(&ctx->mcStream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->mcFork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->mcJoin, hipEventDisableTiming) != hipSuccess)
+            return fail(ctx, ALAC_HIP_MemFullError, "creating the second stream");
+        ctx->mcReady = true;
+    }
+    if (side) {
+        (void)hipEventRecord(ctx->mcFork, mainStream);
+        (void)hipStreamWaitEvent(ctx->mcStream, ctx->mcFork, 0);
+    }
+    int32_t rc = ALAC_HIP_noErr;
+    for (int gi = 0; gi < 2 && rc == ALAC_HIP_noErr; gi++) {
+        const McGroup &G = M.g[gi];
+        if (!G.count) continue;
+        hipStream_t st = (side && gi == 1) ? ctx->mcStream : mainStream;
+        const alac_hip_format gf = element_format(fmt, G.channels);
+        const uint64_t elemPcm = (uint64_t)num_packets * fmt->frame_size * G.channels * bps;
+        for (uint32_t k = 0; k < G.count; k++)
+            launch_mc_gather((const uint8_t *)d_pcm, ws + G.gather + k * elemPcm, d_num_samples, num_packets, fmt->frame_size,
+                             fmt->num_channels, M.el[G.elem[k]].first, G.channels, bps, st);
+        uint32_t *ns = d_num_samples ? (uint32_t *)(ws + G.ns) : nullptr;
+        uint32_t *seg = d_seg_first ? (uint32_t *)(ws + G.seg) : nullptr;
+        launch_mc_tables(d_num_samples, num_packets, d_seg_first, num_segments, G.count, ns, seg, st);
+        // coefficient rows: the caller's [element][segment][64] <-> the batch's [k][segment][64]
+        int16_t *gstate = d_state ? (int16_t *)(ws + G.state) : nullptr;
+        const uint64_t rowBytes = (uint64_t)num_segments * ALAC_HIP_STATE_INT16 * 2;
+        if (gstate && state_in)
+            for (uint32_t k = 0; k < G.count; k++)
+                (void)hipMemcpyAsync((uint8_t *)gstate + k * rowBytes, (const uint8_t *)d_state + G.elem[k] * rowBytes, rowBytes,
+                                     hipMemcpyDeviceToDevice, st);
+        ctx->stream = st;
+        rc = encode_core(ctx, &gf, ws + G.gather, ns, G.count * num_packets, seg, G.count * num_segments, gstate, state_in,
+                         ws + G.sub, G.subBytes, ws + G.out, G.outCap, (uint32_t *)(ws + G.sizes), (uint64_t *)(ws + G.offs),
+                         false);
+        ctx->stream = mainStream;
+        if (gstate && rc == ALAC_HIP_noErr)
+            for (uint32_t k = 0; k < G.count; k++)
+                (void)hipMemcpyAsync((uint8_t *)d_state + G.elem[k] * rowBytes, (const uint8_t *)gstate + k * rowBytes, rowBytes,
+                                     hipMemcpyDeviceToDevice, st);
+    }
+    if (side) {
+        (void)hipEventRecord(ctx->mcJoin, ctx->mcStream);
+        (void)hipStreamWaitEvent(mainStream, ctx->mcJoin, 0);
+    }
+    if (rc != ALAC_HIP_noErr) return rc;
     McSpliceArgs sa;
     sa.numElements = M.numElements;
     sa.numPackets = num_packets;
     for (uint32_t e = 0; e < M.numElements; e++) {
-        const alac_hip_format ef = element_format(fmt, M.el[e].channels);
-        launch_mc_gather((const uint8_t *)d_pcm, ws + M.gather, d_num_samples, num_packets, fmt->frame_size,
-                         fmt->num_channels, M.el[e].first, M.el[e].channels, bytes_per_sample(fmt->bit_depth), ctx->stream);
-        // coefficient rows: [element][segment][64]
-        int16_t *st = d_state ? d_state + (uint64_t)e * num_segments * ALAC_HIP_STATE_INT16 : nullptr;
-        const int32_t rc = encode_core(ctx, &ef, ws + M.gather, d_num_samples, num_packets, d_seg_first, num_segments, st,
-                                       state_in, ws + M.sub, M.subBytes, ws + M.out[e], M.outCap[e],
-                                       (uint32_t *)(ws + M.sizes[e]), (uint64_t *)(ws + M.offs[e]), false);
-        if (rc != ALAC_HIP_noErr) return rc;
+        const McGroup &G = M.g[M.groupOf[e]];
         sa.el[e] = M.el[e];
-        sa.src[e] = ws + M.out[e];
-        sa.srcOffsets[e] = (const uint64_t *)(ws + M.offs[e]);
+        sa.src[e] = ws + G.out;
+        sa.srcOffsets[e] = (const uint64_t *)(ws + G.offs) + (uint64_t)M.indexInGroup[e] * num_packets;
     }
     sa.elemBits = (uint32_t *)(ws + M.elemBits);
     sa.packetBytes = d_packet_bytes;
     sa.offsets = d_packet_offsets;
     sa.out = d_out;
-    launch_mc_splice(sa, ctx->stream);
+    launch_mc_splice(sa, mainStream);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "splice launch", e);
     return ALAC_HIP_noErr;

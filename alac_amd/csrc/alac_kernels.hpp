@@ -157,6 +157,10 @@ struct McSpliceArgs {
 void launch_mc_gather(const uint8_t *pcm, uint8_t *out, const uint32_t *numSamples, uint32_t numPackets,
                       uint32_t frameSize, uint32_t numChannels, uint32_t first, uint32_t channels, uint32_t bytesPerSample,
                       hipStream_t st);
+// the per-packet sample counts and the segment table of `count` elements batched behind each other
+// (sub-packet k * numPackets + p); either input may be null (then its output is not written)
+void launch_mc_tables(const uint32_t *numSamples, uint32_t numPackets, const uint32_t *segFirst, uint32_t numSegments,
+                      uint32_t count, uint32_t *numSamplesOut, uint32_t *segFirstOut, hipStream_t st);
 // sizes + exclusive scan + bit-granular concatenation of the element packets
 void launch_mc_splice(const McSpliceArgs &a, hipStream_t st);
 void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st);

@@ -50,6 +50,17 @@ __global__ __launch_bounds__(256) void k_mc_gather(const uint8_t *pcm, uint8_t *
     for (uint32_t b = 0; b < n; b++) dst[b] = src[b];
 }
 
+__global__ __launch_bounds__(256) void k_mc_tables(const uint32_t *numSamples, uint32_t numPackets, const uint32_t *segFirst,
+                                                   uint32_t numSegments, uint32_t count, uint32_t *nsOut, uint32_t *segOut)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (numSamples && i < (uint64_t)count * numPackets) nsOut[i] = numSamples[i % numPackets];
+    if (segFirst && i <= (uint64_t)count * numSegments)
+        segOut[i] = i == (uint64_t)count * numSegments
+                        ? count * numPackets
+                        : (uint32_t)(i / numSegments) * numPackets + segFirst[i % numSegments];
+}
+
 __global__ __launch_bounds__(256) void k_mc_sizes(McSpliceArgs A)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -136,6 +147,15 @@ void launch_mc_gather(const uint8_t *pcm, uint8_t *out, const uint32_t *numSampl
     const uint64_t totalFrames = (uint64_t)numPackets * frameSize;
     hipLaunchKernelGGL(k_mc_gather, dim3((uint32_t)((totalFrames + 255) / 256)), dim3(256), 0, st, pcm, out, numSamples,
                        totalFrames, frameSize, numChannels, first, channels, bytesPerSample);
+}
+
+void launch_mc_tables(const uint32_t *numSamples, uint32_t numPackets, const uint32_t *segFirst, uint32_t numSegments,
+                      uint32_t count, uint32_t *numSamplesOut, uint32_t *segFirstOut, hipStream_t st)
+{
+    if (!numSamples && !segFirst) return;
+    const uint64_t n = (uint64_t)count * numPackets + 1;
+    hipLaunchKernelGGL(k_mc_tables, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, numSamples, numPackets, segFirst,
+                       numSegments, count, numSamplesOut, segFirstOut);
 }
 
 void launch_mc_splice(const McSpliceArgs &a, hipStream_t st)
