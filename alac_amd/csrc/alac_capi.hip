@@ -204,7 +204,7 @@ McLayout mc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t numSe
 }
 
 struct DecLayout {
-    uint64_t recs, resid, words, capWords, prog, total;
+    uint64_t recs, resid, words, capWords, prog, elemBit, mismatch, total;
     uint32_t maxElems;
 };
 
@@ -219,10 +219,14 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
     off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
     // the stream re-staged as MSB-first words, zero padded (alac_decode_v1.hip): every packet at its largest
     L.words = off;
-    L.capWords = f->num_channels > 2 ? 0 : ((uint64_t)numPackets * max_output_bytes(f, 1) + 3) / 4 + 64;
+    L.capWords = ((uint64_t)numPackets * max_output_bytes(f, 1) + 3) / 4 + 64;
     off = align_up(off + L.capWords * 4, 256);
     L.prog = off;
     off = align_up(off + (uint64_t)numPackets * 8, 256);
+    L.elemBit = off;
+    off = align_up(off + (uint64_t)numPackets * 4, 256);
+    L.mismatch = off;
+    off = align_up(off + 4, 256);
     L.total = off;
     return L;
 }
@@ -741,11 +745,24 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.pcmOut = d_pcm_out;
     da.numSamplesOut = d_num_samples_out;
     da.statusOut = d_status;
-    // element sequences (> 2 channels) run on the lane decoder: the position of element k + 1 is only known once
-    // element k is entropy-decoded
-    hipError_t e = (use_lane_decoder() || fmt.num_channels > 2)
-                       ? launch_decode(da, ctx->stream)
-                       : launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream);
+    hipError_t e;
+    if (use_lane_decoder()) {
+        e = launch_decode(da, ctx->stream);
+    } else if (fmt.num_channels > 2) {
+        // one pass per element of the channel count's sequence (the position of element k + 1 is only known once
+        // element k is entropy-decoded); a stream with another sequence is decoded again by the lane decoder, which
+        // follows whatever the packets carry.  This is the one place where the call waits for the GPU.
+        McElement el[kMaxChannels];
+        const uint32_t nel = channel_elements(fmt.num_channels, el);
+        e = launch_decode_v1_elements(da, el, nel, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog),
+                                      (uint32_t *)(ws + L.elemBit), (uint32_t *)(ws + L.mismatch), ctx->stream);
+        uint32_t mismatch = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&mismatch, ws + L.mismatch, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && mismatch) e = launch_decode(da, ctx->stream);
+    } else {
+        e = launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream);
+    }
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "decode launch", e);
     return ALAC_HIP_noErr;
 }

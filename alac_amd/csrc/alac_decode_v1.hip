@@ -109,6 +109,12 @@ struct DecV1Args {
     int32_t *plane;          // [packet][channel][frameSize]
     uint32_t *prog;          // fused launch: [packet][2] residuals completed per channel (0xffffffff = all)
     uint32_t pubMask;        // the entropy lanes publish every (pubMask + 1) rounds of 16 symbols
+    // element rounds of a > 2-channel stream (launch_decode_v1_elements): round r decodes element r of every packet
+    // as a mono / stereo packet that starts elemBit[p] bits into packet p and leaves the element's end there
+    uint32_t *elemBit;       // null for mono / stereo streams
+    uint32_t round;
+    uint32_t outChannels;    // interleaved channels of the output frame (= element channels for mono / stereo)
+    uint32_t outFirst;       // output channel of the element's first channel
 };
 
 // lane states of the entropy kernel
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     const uint8_t *base = A.stream + off;
     DecRec *rec = A.recs + (live ? p : 0);
 
-    uint64_t hpos = 0;
+    uint64_t hpos = (live && V.elemBit) ? V.elemBit[p] : 0;
     uint32_t numSamples = A.frameSize, ech = 0, shb = 0, chanBits = 0, esc = 0;
-    int32_t status = 0;
+    int32_t status = (live && V.round > 0) ? A.statusOut[p] : 0;  // a packet that failed in an earlier round stays failed
     uint32_t pbU = A.pb, pbV = A.pb;
     DecRec R;
     R.numSamples = 0;
@@ -242,7 +248,10 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         rec->status = status;
         rec->pad = (uint32_t)hpos;  // first payload bit (entropy coded or raw), from the packet start
         A.statusOut[p] = status;
-        A.numSamplesOut[p] = status == 0 ? R.numSamples : 0;
+        if (V.round == 0 || haveElement || status != 0) A.numSamplesOut[p] = status == 0 ? R.numSamples : 0;
+        // where the next element starts: known here for an uncompressed element, left by the entropy lane otherwise
+        if (V.elemBit && status == 0 && haveElement && R.escape)
+            V.elemBit[p] = (uint32_t)(hpos + (uint64_t)R.numSamples * R.elementChannels * A.bitDepth);
     }
     (void)pbU;
     (void)pbV;
@@ -280,6 +289,7 @@ struct EntLane {
     uint32_t F;            // first word (relative to the packet's first staged word) not yet in the ring
     uint32_t active;       // still decoding
     uint32_t chan, c, mb, zmode, pb;
+    uint32_t endPos;       // bits from the packet start to the end of the element's last channel
     int32_t status;
     int32_t *row;          // row of the channel being decoded
 };
@@ -421,6 +431,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                             E.pb = pbV;
                             E.row += A.frameSize;
                         } else {
+                            E.endPos = bw_pos(bw) - bit0;
                             E.active = 0;
                         }
                     }
@@ -491,6 +502,7 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
     E.zmode = 0;
     E.pb = pbU;
     E.status = status0;
+    E.endPos = 0;
     E.row = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
 
     uint32_t *prog = (PUB && live) ? V.prog + (uint64_t)p * 2 : nullptr;
@@ -504,6 +516,7 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
         A.statusOut[p] = E.status;
         A.numSamplesOut[p] = 0;
     }
+    if (coded && V.elemBit && E.status == 0) V.elemBit[p] = E.endPos;
 }
 
 __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
@@ -704,12 +717,16 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
     const uint32_t p = blockIdx.y;
     const DecRec *rec = A.recs + p;
     if (rec->status != 0) return;
-    const uint32_t n = rec->numSamples, shb = rec->bytesShifted;
+    // element rounds: a packet that ended before this element leaves these channels zero (codec/ALACDecoder.cu:971-998)
+    const bool absent = V.elemBit && rec->elementChannels == 0;
+    const uint32_t n = absent ? (V.round ? A.numSamplesOut[p] : A.frameSize) : rec->numSamples;
+    const uint32_t shb = absent ? 0 : rec->bytesShifted;
     const int32_t mixRes = rec->mixRes, mixBits = rec->mixBits;
     const int32_t *u = V.plane + (uint64_t)p * CH * A.frameSize;
     const int32_t *v = u + A.frameSize;
     constexpr uint32_t BPS = bytes_per_sample(DEPTH);
-    uint8_t *out = A.pcmOut + (uint64_t)p * A.frameSize * CH * BPS;
+    const uint32_t och = V.outChannels;
+    uint8_t *out = A.pcmOut + ((uint64_t)p * A.frameSize * och + V.outFirst) * BPS;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
         int32_t l, r = 0;
         if constexpr (CH == 2) {
@@ -731,8 +748,8 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
             l = (int32_t)(((uint32_t)l << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
             if constexpr (CH == 2) r = (int32_t)(((uint32_t)r << (shb * 8)) | read_bits(base, nbytes, sp, shb * 8));
         }
-        uint8_t *q = out + (uint64_t)j * CH * BPS;
-        if constexpr (DEPTH == 16 && CH == 2) {
+        uint8_t *q = out + (uint64_t)j * och * BPS;
+        if (DEPTH == 16 && CH == 2 && och == 2) {
             *(uint32_t *)q = ((uint32_t)(uint16_t)l) | ((uint32_t)r << 16);
         } else {
             put_sample<DEPTH>(q, l);
@@ -752,30 +769,19 @@ static void launch_unmix_v1(const DecV1Args &V, hipStream_t st)
         hipLaunchKernelGGL((k_dec_unmix<DEPTH, 1>), grid, dim3(256), 0, st, V);
 }
 
-hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
-                            hipStream_t st)
+// everything after the staging of the stream: one pass of the pipeline over the elements V describes
+static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
 {
-    if (da.numPackets == 0) return hipSuccess;
-    DecV1Args V;
-    V.d = da;
-    V.words = words;
-    V.capWords = capWords;
-    V.plane = plane;
-    V.prog = prog;
-    {
-        static const uint32_t pm = [] { const char *v = getenv("ALAC_HIP_DEC_PUBMASK"); return v ? (uint32_t)atoi(v) : 31u; }();
-        V.pubMask = pm;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
-    }
+    const DecodeArgs &da = V.d;
     const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
-    (void)hipMemsetAsync(plane, 0, planeBytes, st);  // zero runs only move the index (k_dec_entropy)
-    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
+    (void)hipMemsetAsync(V.plane, 0, planeBytes, st);  // zero runs only move the index (k_dec_entropy)
     hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
     hipLaunchKernelGGL(k_dec_raw, dim3((da.frameSize + 1023) / 1024, da.numPackets), dim3(256), 0, st, V);
     const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
     const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
     static const bool fused = [] { const char *v = getenv("ALAC_HIP_DEC_FUSED"); return !(v && v[0] == '0'); }();
     if (fused) {
-        (void)hipMemsetAsync(prog, 0, (size_t)da.numPackets * 8, st);
+        (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
         hipLaunchKernelGGL(k_dec_fused, dim3(nEnt + nUnpc), dim3(64), 0, st, V, nEnt);
     } else {
         hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
@@ -789,6 +795,63 @@ hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capW
     case 32: launch_unmix_v1<32>(V, st); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog)
+{
+    DecV1Args V;
+    V.d = da;
+    V.words = words;
+    V.capWords = capWords;
+    V.plane = plane;
+    V.prog = prog;
+    static const uint32_t pm = [] { const char *v = getenv("ALAC_HIP_DEC_PUBMASK"); return v ? (uint32_t)atoi(v) : 31u; }();
+    V.pubMask = pm;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
+    V.elemBit = nullptr;
+    V.round = 0;
+    V.outChannels = da.numChannels;
+    V.outFirst = 0;
+    return V;
+}
+
+hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
+                            hipStream_t st)
+{
+    if (da.numPackets == 0) return hipSuccess;
+    const DecV1Args V = decode_v1_args(da, words, capWords, plane, prog);
+    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
+    return decode_v1_pass(V, st);
+}
+
+// counts the packets whose status is `code` (the element-sequence mismatch of launch_decode_v1_elements)
+__global__ void k_dec_count_status(const int32_t *status, uint32_t n, int32_t code, uint32_t *count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && status[i] == code) atomicAdd(count, 1u);
+}
+
+hipError_t launch_decode_v1_elements(const DecodeArgs &da, const McElement *el, uint32_t numElements, uint32_t *words,
+                                     uint64_t capWords, int32_t *plane, uint32_t *prog, uint32_t *elemBit,
+                                     uint32_t *mismatch, hipStream_t st)
+{
+    if (da.numPackets == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
+    (void)hipMemsetAsync(elemBit, 0, (size_t)da.numPackets * 4, st);
+    (void)hipMemsetAsync(mismatch, 0, 4, st);
+    for (uint32_t r = 0; r < numElements; r++) {
+        DecodeArgs dr = da;
+        dr.numChannels = el[r].channels;  // this round's elements as mono / stereo packets
+        DecV1Args V = decode_v1_args(dr, words, capWords, plane, prog);
+        V.elemBit = elemBit;
+        V.round = r;
+        V.outChannels = da.numChannels;
+        V.outFirst = el[r].first;
+        const hipError_t e = decode_v1_pass(V, st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_dec_count_status, dim3((da.numPackets + 255) / 256), dim3(256), 0, st, da.statusOut, da.numPackets,
+                       -4, mismatch);
     return hipGetLastError();
 }
 

@@ -165,6 +165,14 @@ void launch_mc_tables(const uint32_t *numSamples, uint32_t numPackets, const uin
 void launch_mc_splice(const McSpliceArgs &a, hipStream_t st);
 void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st);
 
+// a stream of 3..8 channels on the second-generation decoder: one pass per element of the channel count's element
+// sequence, element r of every packet decoded as the mono / stereo packet that starts where element r - 1 ended
+// (elemBit: numPackets uint32 of scratch).  Packets whose elements are not that sequence end with status -4 and are
+// counted in *mismatch (device): the caller then decodes the batch with launch_decode, which follows any sequence.
+hipError_t launch_decode_v1_elements(const DecodeArgs &da, const McElement *el, uint32_t numElements, uint32_t *words,
+                                     uint64_t capWords, int32_t *plane, uint32_t *prog, uint32_t *elemBit,
+                                     uint32_t *mismatch, hipStream_t st);
+
 // ---- stage-level ----
 hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
                            int16_t *coefs, int32_t numactive, uint32_t chanbits, uint32_t denshift,

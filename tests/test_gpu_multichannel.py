@@ -94,3 +94,56 @@ def test_chained_segments(gpu_ctx, oracle, channels, depth):
         assert np.array_equal(whole[off:off + len(ref)], ref), s
         assert np.array_equal(np.concatenate([got[p] for p in range(a, b)]), ref), s
         off += len(ref)
+
+
+def test_foreign_element_sequences_and_short_packets(gpu_ctx, oracle):
+    """the decoder follows whatever elements a packet carries (codec/ALACDecoder.cu:600-990), not only the sequence
+    this encoder writes: CPE+SCE and SCE+SCE+SCE for a 3-channel cookie (served by the lane decoder after the
+    element rounds report the mismatch), a packet that ends after its first element (remaining channels zero),
+    an LFE tag, and a truncated packet (status -50)"""
+    import torch
+    from oracle_lib import splice_elements
+    depth, n = 16, 4
+    f1, f2, f3 = (alac_amd.make_format(4096, depth, c) for c in (1, 2, 3))
+    mono = [alac_amd.synth_pcm(3 + 8 * k, n, f1) for k in range(3)]
+    stereo = alac_amd.synth_pcm(5, n, f2)
+
+    def packets(pcm, ch):
+        enc = oracle.encoder(4096, depth, ch)
+        s, z = enc.encode_stream(pcm, n * 4096, 1)
+        o = np.concatenate([[0], np.cumsum(z)]).astype(np.int64)
+        return [s[o[p]:o[p + 1]] for p in range(n)]
+
+    pm = [packets(m, 1) for m in mono]
+    ps = packets(stereo, 2)
+    cookie = oracle.encoder(4096, depth, 3).cookie()
+    dec = oracle.decoder(cookie)
+
+    def lfe(pk):  # ID_LFE (3) instead of ID_SCE (0) in the first 3 bits
+        q = pk.copy()
+        q[0] |= 0x60
+        return q
+
+    cases = {
+        "cpe_sce": [splice_elements([(ps[p], 0), (pm[0][p], 0)]) for p in range(n)],
+        "three_sce": [splice_elements([(pm[0][p], 0), (pm[1][p], 1), (pm[2][p], 2)]) for p in range(n)],
+        "short": [splice_elements([(pm[0][p], 0)]) if p % 2 else splice_elements([(pm[0][p], 0), (ps[p], 0)])
+                  for p in range(n)],
+        "lfe_first": [splice_elements([(lfe(pm[0][p]), 0), (ps[p], 0)]) for p in range(n)],
+    }
+    trunc = [splice_elements([(pm[0][p], 0), (ps[p], 0)]) for p in range(n)]
+    trunc[2] = trunc[2][:len(trunc[2]) // 2]
+    cases["truncated"] = trunc
+    for name, pks in cases.items():
+        stream = np.concatenate(pks)
+        offs = np.concatenate([[0], np.cumsum([len(q) for q in pks])]).astype(np.int64)
+        out, ns, st, _ = gpu_ctx.decode(cookie, torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), n)
+        gpu_ctx.synchronize()
+        out, ns, st = out.cpu().numpy(), ns.cpu().numpy(), st.cpu().numpy()
+        for p in range(n):
+            want_st, want, want_n = dec.decode_packet(pks[p], f3.bytes_per_frame)
+            assert st[p] == want_st, (name, p)
+            if want_st == 0:
+                assert ns[p] == want_n, (name, p)
+                a = p * f3.packet_bytes
+                assert np.array_equal(out[a:a + want_n * f3.bytes_per_frame], want), (name, p)
