@@ -368,6 +368,97 @@ Bytes build_wave(double sampleRate, uint32_t channels, uint32_t bits, const uint
     return o;
 }
 
+// ---- the cookie outside CAF: ALACMagicCookieDescription.txt:177-238 ----
+
+namespace {
+const uint32_t kFrma = 0x66726d61u, kAlac = 0x616c6163u, kStsd = 0x73747364u;
+void put_be16(Bytes &o, uint32_t v)
+{
+    o.push_back((uint8_t)(v >> 8));
+    o.push_back((uint8_t)v);
+}
+}  // namespace
+
+Bytes wrap_legacy_cookie(const Bytes &cookie)
+{
+    Bytes o;
+    put_be32(o, 12);  // format atom
+    put_be32(o, kFrma);
+    put_be32(o, kAlac);
+    put_be32(o, (uint32_t)(12 + cookie.size()));  // ALAC specific info: 36 = 12 + sizeof(ALACSpecificConfig)
+    put_be32(o, kAlac);
+    put_be32(o, 0);   // version / flags
+    o.insert(o.end(), cookie.begin(), cookie.end());
+    put_be32(o, 8);   // terminator atom
+    put_be32(o, 0);
+    return o;
+}
+
+Bytes unwrap_cookie(const Bytes &c)
+{
+    size_t pos = 0, end = c.size();
+    bool wrapped = false;
+    if (end - pos >= 12 && be32(&c[pos + 4]) == kFrma) pos += 12, wrapped = true;  // codec/ALACDecoder.cu:123-128
+    if (end - pos >= 12 && be32(&c[pos + 4]) == kAlac) {                           // :129-134
+        const uint32_t infoSize = be32(&c[pos]);
+        pos += 12;
+        if (infoSize >= 12 + 24 && pos + (infoSize - 12) <= end) end = pos + (infoSize - 12);
+        wrapped = true;
+    }
+    if (!wrapped && end >= 8 && be32(&c[end - 8]) == 8 && be32(&c[end - 4]) == 0 && (end == 32 || end == 56)) end -= 8;
+    const size_t n = end - pos;
+    if (n < 24) return Bytes();
+    // 24-byte config, or config + 'chan' atom + layout
+    const size_t take = (n >= 48 && be32(&c[pos + 28]) == 0x6368616eu) ? 48 : 24;
+    return Bytes(c.begin() + pos, c.begin() + pos + take);
+}
+
+Bytes build_alac_sample_description(const Bytes &cookie, uint32_t channels, uint32_t bits, uint32_t sampleRate)
+{
+    Bytes o;
+    const uint32_t entry = 36 + 12 + (uint32_t)cookie.size();
+    put_be32(o, 16 + entry);  // SoundDescriptionBox
+    put_be32(o, kStsd);
+    put_be32(o, 0);           // version / flags
+    put_be32(o, 1);           // entry count
+    put_be32(o, entry);       // AudioSampleEntry
+    put_be32(o, kAlac);
+    for (int i = 0; i < 6; i++) o.push_back(0);  // reserved
+    put_be16(o, 1);           // data reference index
+    put_be32(o, 0);           // reserved[2]
+    put_be32(o, 0);
+    put_be16(o, channels);
+    put_be16(o, bits);
+    put_be16(o, 0);           // predefined
+    put_be16(o, 0);           // reserved
+    put_be32(o, sampleRate << 16);  // 16.16 (ISO/IEC 14496-12 AudioSampleEntry); rates >= 65536 wrap, the cookie is exact
+    put_be32(o, 12 + (uint32_t)cookie.size());  // ALAC specific info (full box)
+    put_be32(o, kAlac);
+    put_be32(o, 0);
+    o.insert(o.end(), cookie.begin(), cookie.end());
+    return o;
+}
+
+std::string parse_alac_sample_description(const Bytes &b, Bytes &cookie, uint32_t &channels, uint32_t &bits,
+                                          uint32_t &sampleRate16_16)
+{
+    if (b.size() < 16 + 36 + 12 + 24) return "sample description too short";
+    if (be32(&b[4]) != kStsd || be32(&b[0]) > b.size()) return "not a sample description box";
+    if (be32(&b[12]) < 1) return "no sample entry";
+    const size_t e = 16;
+    const uint32_t entry = be32(&b[e]);
+    if (be32(&b[e + 4]) != kAlac) return "sample entry is not 'alac'";
+    if (entry < 36 + 12 + 24 || e + entry > b.size()) return "bad sample entry size";
+    channels = ((uint32_t)b[e + 24] << 8) | b[e + 25];
+    bits = ((uint32_t)b[e + 26] << 8) | b[e + 27];
+    sampleRate16_16 = be32(&b[e + 32]);
+    const size_t info = e + 36;
+    const uint32_t infoSize = be32(&b[info]);
+    if (be32(&b[info + 4]) != kAlac || infoSize < 12 + 24 || info + infoSize > e + entry) return "bad ALAC specific info";
+    cookie.assign(b.begin() + info + 12, b.begin() + info + infoSize);
+    return "";
+}
+
 Bytes build_pcm_caf(double sampleRate, uint32_t channels, uint32_t bits, const uint8_t *pcm, uint64_t pcmBytes)
 {
     // main.cu:675-693 with SetOutputFormat's decode branch (:303-331) and WriteCAFFdescChunk's lpcm flags (:73-83)

@@ -66,6 +66,20 @@ std::string parse_alac_caf(const Bytes &file, const InputInfo &info, AlacCafCont
 Bytes build_wave(double sampleRate, uint32_t channels, uint32_t bitsPerChannel, const uint8_t *pcm, uint64_t pcmBytes);
 Bytes build_pcm_caf(double sampleRate, uint32_t channels, uint32_t bitsPerChannel, const uint8_t *pcm, uint64_t pcmBytes);
 
+/* ---- the magic cookie outside CAF (ALACMagicCookieDescription.txt:177-238) ----
+ * Legacy cookie: 'frma' format atom (12) + ALAC specific info header (12) + the cookie + terminator atom (8); what
+ * ALACDecoder::Init skips in front of the config (codec/ALACDecoder.cu:123-134). */
+Bytes wrap_legacy_cookie(const Bytes &cookie);
+/* the bare cookie (24 or 48 bytes) out of a bare or legacy-wrapped one; empty if it is neither */
+Bytes unwrap_cookie(const Bytes &cookie);
+/* MP4/M4A: the SoundDescriptionBox 'stsd' with one 'alac' AudioSampleEntry (36 bytes), the 12-byte full-box header of
+ * the ALAC specific info and the cookie as vended (:186-216); all fields big endian, sample rate as the 16.16 value
+ * ISO/IEC 14496-12 defines for the entry (the cookie carries the exact rate). */
+Bytes build_alac_sample_description(const Bytes &cookie, uint32_t channels, uint32_t bitsPerChannel, uint32_t sampleRate);
+/* inverse: cookie + the entry's fields; returns "" or a diagnostic */
+std::string parse_alac_sample_description(const Bytes &stsd, Bytes &cookie, uint32_t &channels, uint32_t &bitsPerChannel,
+                                          uint32_t &sampleRate16_16);
+
 /* byte order of CAF big-endian lpcm -> packed little-endian (main.cu:482-507) */
 void swap_samples_in_place(uint8_t *pcm, uint64_t bytes, uint32_t bitsPerChannel);
 

@@ -70,6 +70,29 @@ uint64_t alacfile_build_pcm_caf(double sample_rate, uint32_t channels, uint32_t 
     return give(build_pcm_caf(sample_rate, channels, bits, pcm, pcm_bytes), out, cap);
 }
 
+/* cookie wrappers / MP4 sample description (ALACMagicCookieDescription.txt:177-238); kind 0 = wrap legacy, 1 = unwrap */
+uint64_t alacfile_cookie(int32_t kind, const uint8_t *cookie, uint32_t size, uint8_t *out, uint64_t cap)
+{
+    Bytes c(cookie, cookie + size);
+    return give(kind == 0 ? wrap_legacy_cookie(c) : unwrap_cookie(c), out, cap);
+}
+
+uint64_t alacfile_build_stsd(const uint8_t *cookie, uint32_t size, uint32_t channels, uint32_t bits, uint32_t rate,
+                             uint8_t *out, uint64_t cap)
+{
+    return give(build_alac_sample_description(Bytes(cookie, cookie + size), channels, bits, rate), out, cap);
+}
+
+/* returns the cookie size (copied to cookie_out, cap 64) or -1; fields3 = channels, bits, rate 16.16 */
+int64_t alacfile_parse_stsd(const uint8_t *box, uint64_t size, uint8_t *cookie_out, uint32_t *fields3)
+{
+    Bytes ck;
+    if (!parse_alac_sample_description(Bytes(box, box + size), ck, fields3[0], fields3[1], fields3[2]).empty() || ck.size() > 64)
+        return -1;
+    memcpy(cookie_out, ck.data(), ck.size());
+    return (int64_t)ck.size();
+}
+
 /* cookie to cookie_out (cap 64), packet sizes to sizes_out (cap max_packets); returns the packet count or -1 */
 int64_t alacfile_parse_alac_caf(const uint8_t *file, uint64_t size, uint8_t *cookie_out, uint32_t *cookie_size,
                                 uint32_t *sizes_out, uint32_t max_packets, uint64_t *data_pos)

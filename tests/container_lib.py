@@ -71,6 +71,24 @@ class Container:
             return None
         return bytes(cookie[:csize.value]), sizes[:n].copy(), dpos.value
 
+    def cookie(self, kind, cookie):
+        out = (C.c_uint8 * 128)()
+        self.lib.alacfile_cookie.restype = C.c_uint64
+        n = self.lib.alacfile_cookie(kind, _u8(cookie), len(cookie), out, C.c_uint64(128))
+        return bytes(out[:n])
+
+    def build_stsd(self, cookie, ch, bits, rate):
+        out = (C.c_uint8 * 256)()
+        self.lib.alacfile_build_stsd.restype = C.c_uint64
+        n = self.lib.alacfile_build_stsd(_u8(cookie), len(cookie), ch, bits, rate, out, C.c_uint64(256))
+        return bytes(out[:n])
+
+    def parse_stsd(self, box):
+        ck, f = (C.c_uint8 * 64)(), (C.c_uint32 * 3)()
+        self.lib.alacfile_parse_stsd.restype = C.c_int64
+        n = self.lib.alacfile_parse_stsd(_u8(box), C.c_uint64(len(box)), ck, f)
+        return None if n < 0 else (bytes(ck[:n]), f[0], f[1], f[2])
+
     def ber(self, v):
         out = (C.c_uint8 * 5)()
         n = self.lib.alacfile_append_ber(C.c_uint32(v), out)

@@ -182,3 +182,28 @@ def test_reference_wav_known_answers(cont, oracle):
     assert got == caf
     back = co.decode_file(caf, True, decode_packet)
     assert back[44:] == wav[info.data_pos:info.data_pos + info.data_size]
+
+
+def test_cookie_outside_caf(cont, oracle):
+    """legacy 'frma' / 'alac' wrapping and the MP4 sample description of ALACMagicCookieDescription.txt:177-238, byte
+    for byte; the decoders (oracle restating codec/ALACDecoder.cu:123-134) accept the wrapped cookie"""
+    import struct
+    for ch in (2, 6):
+        enc = oracle.encoder(4096, 16, ch, 44100)
+        ck = bytes(enc.cookie())
+        assert len(ck) == (24 if ch == 2 else 48)
+        w = cont.cookie(0, ck)
+        assert w == (struct.pack(">I4s4s", 12, b"frma", b"alac") + struct.pack(">I4sI", 12 + len(ck), b"alac", 0) + ck +
+                     struct.pack(">II", 8, 0))
+        assert cont.cookie(1, w) == ck and cont.cookie(1, ck) == ck
+        assert cont.cookie(1, w[12:]) == ck            # 'alac' info without the format atom
+        assert cont.cookie(1, b"\\0" * 10) == b""
+        d = oracle.decoder(np.frombuffer(w, np.uint8))  # Init skips both atoms
+        assert d.h and d.frame == 4096
+        box = cont.build_stsd(ck, ch, 16, 44100)
+        entry = 36 + 12 + len(ck)
+        assert box[:16] == struct.pack(">I4sII", 16 + entry, b"stsd", 0, 1)
+        assert box[16:52] == struct.pack(">I4s6xHIIHHHHI", entry, b"alac", 1, 0, 0, ch, 16, 0, 0, 44100 << 16)
+        assert box[52:64] == struct.pack(">I4sI", 12 + len(ck), b"alac", 0) and box[64:] == ck
+        assert cont.parse_stsd(box) == (ck, ch, 16, 44100 << 16)
+        assert cont.parse_stsd(box[:40]) is None and cont.parse_stsd(b"x" * 100) is None
