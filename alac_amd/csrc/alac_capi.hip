@@ -414,6 +414,7 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
         (void)hipStreamWaitEvent(ctx->mcStream, ctx->mcFork, 0);
     }
     int32_t rc = ALAC_HIP_noErr;
+    hipError_t copyErr = hipSuccess;
     for (int gi = 0; gi < 2 && rc == ALAC_HIP_noErr; gi++) {
         const McGroup &G = M.g[gi];
         if (!G.count) continue;
@@ -430,24 +431,26 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
         int16_t *gstate = d_state ? (int16_t *)(ws + G.state) : nullptr;
         const uint64_t rowBytes = (uint64_t)num_segments * ALAC_HIP_STATE_INT16 * 2;
         if (gstate && state_in)
-            for (uint32_t k = 0; k < G.count; k++)
-                (void)hipMemcpyAsync((uint8_t *)gstate + k * rowBytes, (const uint8_t *)d_state + G.elem[k] * rowBytes, rowBytes,
-                                     hipMemcpyDeviceToDevice, st);
+            for (uint32_t k = 0; k < G.count && copyErr == hipSuccess; k++)
+                copyErr = hipMemcpyAsync((uint8_t *)gstate + k * rowBytes, (const uint8_t *)d_state + G.elem[k] * rowBytes,
+                                         rowBytes, hipMemcpyDeviceToDevice, st);
         ctx->stream = st;
         rc = encode_core(ctx, &gf, ws + G.gather, ns, G.count * num_packets, seg, G.count * num_segments, gstate, state_in,
                          ws + G.sub, G.subBytes, ws + G.out, G.outCap, (uint32_t *)(ws + G.sizes), (uint64_t *)(ws + G.offs),
                          false);
         ctx->stream = mainStream;
         if (gstate && rc == ALAC_HIP_noErr)
-            for (uint32_t k = 0; k < G.count; k++)
-                (void)hipMemcpyAsync((uint8_t *)d_state + G.elem[k] * rowBytes, (const uint8_t *)gstate + k * rowBytes, rowBytes,
-                                     hipMemcpyDeviceToDevice, st);
+            for (uint32_t k = 0; k < G.count && copyErr == hipSuccess; k++)
+                copyErr = hipMemcpyAsync((uint8_t *)d_state + G.elem[k] * rowBytes, (const uint8_t *)gstate + k * rowBytes,
+                                         rowBytes, hipMemcpyDeviceToDevice, st);
     }
     if (side) {
         (void)hipEventRecord(ctx->mcJoin, ctx->mcStream);
         (void)hipStreamWaitEvent(mainStream, ctx->mcJoin, 0);
     }
+    // (the second stream is joined above whatever happened, so the context's stream stays the only one to wait on)
     if (rc != ALAC_HIP_noErr) return rc;
+    if (copyErr != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "coefficient state copy", copyErr);
     McSpliceArgs sa;
     sa.numElements = M.numElements;
     sa.numPackets = num_packets;
