@@ -261,10 +261,9 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
 
 // ---- k_dec_raw: uncompressed (escape) elements are fixed-width fields, i.e. not serial at all: one thread per
 // sample-frame reads its fields straight from the staged words (codec/ALACDecoder.cu:697-727 / :856-896)
-__global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
+__device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_t first, uint32_t step)
 {
     const DecodeArgs &A = V.d;
-    const uint32_t p = blockIdx.y;
     const DecRec *rec = A.recs + p;
     if (rec->status != 0 || !rec->escape || rec->elementChannels == 0) return;
     const uint32_t ech = rec->elementChannels, n = rec->numSamples, w = A.bitDepth;
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
     const uint64_t bitBase = (off & 3) * 8 + rec->pad;
     const uint32_t *words = V.words + (off >> 2);
     int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    for (uint32_t j = first; j < n; j += step) {
         for (uint32_t c = 0; c < ech; c++) {
             const uint64_t b = bitBase + ((uint64_t)j * ech + c) * w;
             const uint32_t i = (uint32_t)(b >> 5), sh = (uint32_t)(b & 31);
@@ -281,6 +280,15 @@ __global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
             (rowU + c * A.frameSize)[j] = (int32_t)(v << (32 - w)) >> (32 - w);
         }
     }
+}
+
+// blocks per packet of the sample-parallel kernels (1-D grids: gridDim.y stops at 65535 packets)
+__device__ __host__ inline uint32_t blocks_per_packet(uint32_t frameSize) { return frameSize > 1024 ? (frameSize + 1023) / 1024 : 1; }
+
+__global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
+{
+    const uint32_t bx = blocks_per_packet(V.d.frameSize);
+    raw_body(V, blockIdx.x / bx, (blockIdx.x % bx) * blockDim.x + threadIdx.x, bx * blockDim.x);
 }
 
 // per-lane state of the entropy kernel
@@ -670,11 +678,14 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
 __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_body<false>(V, blockIdx.x); }
 
 // ---- fused launch: entropy waves first (they are resident before any follower can wait), predictor waves behind
-__global__ __launch_bounds__(64) void k_dec_fused(DecV1Args V, uint32_t nEnt)
+// them; last, one block per packet for the uncompressed elements (nobody waits for those: their dispatch hides under
+// the entropy chain instead of costing a launch of its own)
+__global__ __launch_bounds__(64) void k_dec_fused(DecV1Args V, uint32_t nEnt, uint32_t nUnpc)
 {
     __shared__ uint32_t ring[64 * kWinStride];
     if (blockIdx.x < nEnt) entropy_body<true>(V, ring, blockIdx.x);
-    else unpc_fast_body<true>(V, blockIdx.x - nEnt);
+    else if (blockIdx.x < nEnt + nUnpc) unpc_fast_body<true>(V, blockIdx.x - nEnt);
+    else raw_body(V, blockIdx.x - nEnt - nUnpc, threadIdx.x, 64);
 }
 
 __global__ __launch_bounds__(64) void k_dec_unpc(DecV1Args V)
@@ -714,7 +725,8 @@ template <int DEPTH, int CH>
 __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
 {
     const DecodeArgs &A = V.d;
-    const uint32_t p = blockIdx.y;
+    const uint32_t bx = blocks_per_packet(A.frameSize);
+    const uint32_t p = blockIdx.x / bx;
     const DecRec *rec = A.recs + p;
     if (rec->status != 0) return;
     // element rounds: a packet that ended before this element leaves these channels zero (codec/ALACDecoder.cu:971-998)
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
     constexpr uint32_t BPS = bytes_per_sample(DEPTH);
     const uint32_t och = V.outChannels;
     uint8_t *out = A.pcmOut + ((uint64_t)p * A.frameSize * och + V.outFirst) * BPS;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    for (uint32_t j = (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
         int32_t l, r = 0;
         if constexpr (CH == 2) {
             const int32_t uu = u[j], vv = v[j];
@@ -761,8 +773,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
 template <int DEPTH>
 static void launch_unmix_v1(const DecV1Args &V, hipStream_t st)
 {
-    const uint32_t bx = (V.d.frameSize + 1023) / 1024;
-    dim3 grid(bx ? bx : 1, V.d.numPackets);
+    dim3 grid(blocks_per_packet(V.d.frameSize) * V.d.numPackets);
     if (V.d.numChannels == 2)
         hipLaunchKernelGGL((k_dec_unmix<DEPTH, 2>), grid, dim3(256), 0, st, V);
     else
@@ -776,14 +787,14 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
     const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
     (void)hipMemsetAsync(V.plane, 0, planeBytes, st);  // zero runs only move the index (k_dec_entropy)
     hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
-    hipLaunchKernelGGL(k_dec_raw, dim3((da.frameSize + 1023) / 1024, da.numPackets), dim3(256), 0, st, V);
     const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
     const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
     static const bool fused = [] { const char *v = getenv("ALAC_HIP_DEC_FUSED"); return !(v && v[0] == '0'); }();
     if (fused) {
         (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
-        hipLaunchKernelGGL(k_dec_fused, dim3(nEnt + nUnpc), dim3(64), 0, st, V, nEnt);
+        hipLaunchKernelGGL(k_dec_fused, dim3(nEnt + nUnpc + da.numPackets), dim3(64), 0, st, V, nEnt, nUnpc);
     } else {
+        hipLaunchKernelGGL(k_dec_raw, dim3(blocks_per_packet(da.frameSize) * da.numPackets), dim3(256), 0, st, V);
         hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
         hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
     }

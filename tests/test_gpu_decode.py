@@ -51,3 +51,27 @@ def test_decode_flags_corrupt_packets(gpu_ctx, oracle):
     st = st.cpu().tolist()
     assert st[0] == 0 and st[1] == -50 and st[2] == -50
     assert np.array_equal(out[:fmt.packet_bytes].cpu().numpy(), pcm[:fmt.packet_bytes])
+
+
+@pytest.mark.parametrize("frame", [64, 2048])
+def test_more_packets_than_a_grid_dimension(gpu_ctx, oracle, frame):
+    """70 000 packets in one call (a launch grid's y dimension stops at 65 535): encode -> decode round trip on
+    the GPU, oracle bytes on a sample of the packets"""
+    import torch
+    fmt = alac_amd.make_format(frame, 16, 2)
+    n = 70000
+    pcm = alac_amd.synth_pcm(0, n, fmt)
+    d_pcm = torch.from_numpy(pcm).cuda()
+    b = gpu_ctx.encode(fmt, d_pcm, n)
+    gpu_ctx.synchronize()
+    offs = b["offsets"].cpu().numpy()
+    stream = b["out"][:int(offs[-1])].cpu().numpy()
+    enc = oracle.encoder(frame, 16, 2)
+    for p in (0, 1, 7, 65534, 65535, 65536, 69999):
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], frame)
+        assert np.array_equal(stream[offs[p]:offs[p + 1]], pk), p
+    out, ns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), b["out"], b["offsets"], n)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and int((ns != frame).sum()) == 0
+    assert torch.equal(out, d_pcm)
