@@ -12,9 +12,7 @@
 // The early-exit update walk of the reference ("for k = na-1 .. 0 while del0 keeps its sign",
 // dp_enc.c:143-188) is evaluated without the walk: with t_i = |b_i| >> 9 (del > 0) resp.
 // (|b_i| + 511) >> 9 (del < 0) [= -((-|b_i|) >> 9)], tap k is touched iff
-// |del| > S_k := sum_{i > k} (na - i) * t_i, because the partial sums only grow.  Everything that depends
-// on the input samples alone (b_i, S_k for both signs, sign(b_i)) is off the dependent chain, which is just
-// multiply-add -> (pair add) -> shift/add/sign-extend -> clamp-compare -> coefficient add.
+// |del| > S_k := sum_{i > k} (na - i) * t_i, because the partial sums only grow.
 #pragma once
 
 #include "alac_dev.hpp"
@@ -81,52 +79,47 @@ template <int LPC, bool MASKED>
 __device__ __forceinline__ int32_t lms4_step(int32_t (&a)[4], const int32_t (&w)[4], int32_t tp, int32_t cu,
                                              int32_t liveMask, const LmsLane &L, uint32_t chanbits)
 {
-    // ---- data-only part ----
-    int32_t b[4], sb[4];
-    uint32_t tpos[4], tneg[4];
+    // A wave that has a SIMD to itself pays for every instruction it issues (a wave64 VALU instruction occupies the
+    // SIMD16 for 4 cycles, a dependent one follows after ~4.4-5.5), so the step is written for the fewest
+    // instructions, not for the shortest dependent chain: the residual first, then ONE set of thresholds with the
+    // rounding its sign selects (an earlier version evaluated both roundings ahead of del: 73 instructions per
+    // step against 50 here).
+    int32_t b[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        b[i] = tp - w[i];
-        const int32_t ab = max(b[i], -b[i]);
-        tpos[i] = (uint32_t)ab >> kDenShift;
-        tneg[i] = (uint32_t)(ab + ((1 << kDenShift) - 1)) >> kDenShift;
-        sb[i] = sign3(b[i]);
-        if constexpr (MASKED) sb[i] &= liveMask;  // steps outside [jlo, jhi) leave the coefficients alone
-    }
-    // thresholds: hi[i] = S+_{4h+i}, lo[i] = -S-_{4h+i}: in-lane running sums from the top tap down
-    int32_t hi[4], lo[4];
-    hi[3] = 0;
-    lo[3] = 0;
-#pragma unroll
-    for (int i = 3; i > 0; i--) {
-        hi[i - 1] = (int32_t)__umul24(tpos[i], (uint32_t)L.wg[i]) + hi[i];
-        lo[i - 1] = lo[i] - (int32_t)__umul24(tneg[i], (uint32_t)L.wg[i]);
-    }
-    if constexpr (LPC == 2) {
-        // taps 0..3 also count everything the partner lane (taps 4..7) holds
-        const int32_t totP = (int32_t)__umul24(tpos[0], (uint32_t)L.wg[0]) + hi[0];
-        const int32_t totM = lo[0] - (int32_t)__umul24(tneg[0], (uint32_t)L.wg[0]);
-        const int32_t cP = dpp_xor1(totP) & L.carryMask;
-        const int32_t cM = dpp_xor1(totM) & L.carryMask;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            hi[i] += cP;
-            lo[i] += cM;
-        }
-    }
+    for (int i = 0; i < 4; i++) b[i] = tp - w[i];
     const int32_t p = cu - tp;
-
-    // ---- dependent chain ----
     int32_t s = L.c255;
 #pragma unroll
     for (int i = 0; i < 4; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;
     if constexpr (LPC == 2) s += dpp_xor1(s);
     const int32_t del = __builtin_amdgcn_sbfe(p + (s >> kDenShift), 0, chanbits);
+
+    // coefficient walk: t_i = (|b_i| + rc) >> 9 with rc = 511 for del < 0 (the arithmetic shift of a negative
+    // product rounds away from zero, dp_enc.c:176), tap k is touched iff |del| > S_k
+    const int32_t nd = -del;
+    const int32_t adel = max(del, nd);
+    int32_t nsg = sign3(nd);                // -sign(del): what a touched tap adds per sign(b)
+    if constexpr (MASKED) nsg &= liveMask;  // steps outside [jlo, jhi) leave the coefficients alone
+    const int32_t rc = (del >> 31) & ((1 << kDenShift) - 1);
+    int32_t sb[4];
+    uint32_t t[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int32_t e = med3_i32(del, lo[i], hi[i]) - del;  // < 0: del > S+ ; > 0: del < -S-
-        a[i] = __mul24(sign3(e), sb[i]) + a[i];               // a -= sign(del) * sign(b) on the touched taps
+        sb[i] = sign3(b[i]);
+        t[i] = (uint32_t)(__mul24(sb[i], b[i]) + rc) >> kDenShift;  // |b| = sign(b) * b
     }
+    int32_t S[4];  // in-lane part of S_k, from the top tap down
+    S[3] = 0;
+#pragma unroll
+    for (int i = 3; i > 0; i--) S[i - 1] = (int32_t)__umul24(t[i], (uint32_t)L.wg[i]) + S[i];
+    int32_t adj = adel;
+    if constexpr (LPC == 2) {
+        // taps 0..3 also count everything the partner lane (taps 4..7) holds: |del| > S + c  <=>  |del| - c > S
+        const int32_t tot = (int32_t)__umul24(t[0], (uint32_t)L.wg[0]) + S[0];
+        adj = adel - (dpp_xor1(tot) & L.carryMask);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = __mul24(adj > S[i] ? nsg : 0, sb[i]) + a[i];
     return del;
 }
 
