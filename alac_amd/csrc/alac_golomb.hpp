@@ -117,12 +117,13 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
     const uint32_t capf = sw & ((g.nz + 1u) >> 16);                    // the run just reached 65535
     const uint32_t cl = inr & (nzf | capf);                            // the run ends before / at this residual
     // (B) a scalar test and branch over the (rare) close; no exec-mask change on the way that skips it
-    if (__builtin_amdgcn_ballot_w64(cl != 0) != 0) {
-        if (cl) {
-            golf_close_run<WRITE>(g, recip);
-            if (capf) g.zmode = 0;
-        }
+    if (cl) {
+        golf_close_run<WRITE>(g, recip);
+        if (capf) g.zmode = 0;
     }
+    // keep (C) ONE copy behind the join: left alone, the compiler threads "mb = 0 after a close" into a second copy
+    // of the k computation and pays for it with an exec-mask dance on the path that skips the close
+    asm volatile("" : "+v"(g.mb));
     // (C) ag_enc.c:285-331.  Where every lane of the wave is inside its stream (!CHECKED) the symbol is computed
     // by ALL lanes and a lane that swallowed a zero simply keeps its state and appends nothing: an exec-masked
     // region costs a lone wave a save/branch/restore sequence worth a dozen instructions, the selects cost six.

@@ -160,42 +160,36 @@ __device__ __forceinline__ LmsDecLane make_dec_lane(int lane, int na)
 __device__ __forceinline__ int32_t lms4_step_dec(int32_t (&a)[4], int32_t (&w)[4], int32_t &tp, int32_t del,
                                                  const LmsDecLane &L, uint32_t chanbits)
 {
-    int32_t b[4], sb[4];
-    uint32_t tpos[4], tneg[4];
+    int32_t b[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        b[i] = tp - w[i];
-        const int32_t ab = max(b[i], -b[i]);
-        tpos[i] = (uint32_t)ab >> kDenShift;
-        tneg[i] = (uint32_t)(ab + ((1 << kDenShift) - 1)) >> kDenShift;
-        sb[i] = sign3(b[i]);
-    }
-    int32_t hi[4], lo[4];
-    hi[3] = 0;
-    lo[3] = 0;
-#pragma unroll
-    for (int i = 3; i > 0; i--) {
-        hi[i - 1] = (int32_t)__umul24(tpos[i], (uint32_t)L.wg[i]) + hi[i];
-        lo[i - 1] = lo[i] - (int32_t)__umul24(tneg[i], (uint32_t)L.wg[i]);
-    }
-    const int32_t totP = (int32_t)__umul24(tpos[0], (uint32_t)L.wg[0]) + hi[0];
-    const int32_t totM = lo[0] - (int32_t)__umul24(tneg[0], (uint32_t)L.wg[0]);
-    const int32_t cP = dpp_xor1(totP) & L.carryMask;
-    const int32_t cM = dpp_xor1(totM) & L.carryMask;
-
-    // dependent chain: out[j] = sext(del + top + ((denhalf - sum) >> 9)), -((256 - s) >> 9) == (s + 255) >> 9
+    for (int i = 0; i < 4; i++) b[i] = tp - w[i];
+    // out[j] = sext(del + top + ((denhalf - sum) >> 9)), -((256 - s) >> 9) == (s + 255) >> 9
     int32_t s = L.c255;
 #pragma unroll
     for (int i = 0; i < 4; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;
     s += dpp_xor1(s);
     const int32_t out = __builtin_amdgcn_sbfe(del + tp - (s >> kDenShift), 0, chanbits);
 
-    // coefficient update, driven by del (dp_dec.c:143-188 == the encoder's walk)
+    // coefficient update, driven by del (dp_dec.c:143-188 == the encoder's walk, same form as lms4_step)
+    const int32_t nd = -del;
+    const int32_t adel = max(del, nd);
+    const int32_t nsg = sign3(nd);
+    const int32_t rc = (del >> 31) & ((1 << kDenShift) - 1);
+    int32_t sb[4];
+    uint32_t t[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int32_t e = med3_i32(del, lo[i] + cM, hi[i] + cP) - del;
-        a[i] = __mul24(sign3(e), sb[i]) + a[i];
+        sb[i] = sign3(b[i]);
+        t[i] = (uint32_t)(__mul24(sb[i], b[i]) + rc) >> kDenShift;
     }
+    int32_t S[4];
+    S[3] = 0;
+#pragma unroll
+    for (int i = 3; i > 0; i--) S[i - 1] = (int32_t)__umul24(t[i], (uint32_t)L.wg[i]) + S[i];
+    const int32_t tot = (int32_t)__umul24(t[0], (uint32_t)L.wg[0]) + S[0];
+    const int32_t adj = adel - (dpp_xor1(tot) & L.carryMask);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = __mul24(adj > S[i] ? nsg : 0, sb[i]) + a[i];
     // windows: lane 0's oldest sample moves to lane 1, the oldest sample of the last active tap is the next top
     const int32_t x = dpp_xor1(w[3]) & L.feed;
     tp = L.topMine ? w[3] : x;
