@@ -24,7 +24,7 @@ __device__ __forceinline__ void gol_table_init(uint32_t *recip, int tid)
 }
 
 struct GolF {
-    uint32_t mb, zmode, inrun, nz, bits;
+    uint32_t mb, zmode, inrun, nz1, bits;  // nz1 = zeros swallowed by the open run + 1 (so that ">> 16" is the cap test)
     uint64_t acc;      // the most recent bits, right aligned; the low `nacc` of them are not yet a full word
     uint32_t nacc, wleft;
     uint32_t *wp;      // where the word being assembled goes
@@ -35,7 +35,7 @@ __device__ __forceinline__ void golf_reset(GolF &g)
     g.mb = kMB0;
     g.zmode = 0;
     g.inrun = 0;
-    g.nz = 0;
+    g.nz1 = 1;
     g.bits = 0;
     g.acc = 0;
     g.nacc = 0;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
 {
     const uint32_t k = (uint32_t)(lead(g.mb) - 24 + (int32_t)((g.mb + 16u) >> 6));
     const uint32_t mz = (1u << k) - 1;  // & wb is the identity: k <= 8 < kb
-    const uint32_t nz = g.nz;
+    const uint32_t nz = g.nz1 - 1;
     const uint32_t div = __umulhi(nz, recip[k]);  // nz < 2^16, mz < 2^8
     uint32_t numBits, value;
     if (div >= kMaxPrefix) {
@@ -110,14 +110,17 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
     // (A) ag_enc.c:333-349, on 0/1 flags in vector registers (boolean chains through scalar masks cost a lone
     // wave three times as many instructions): del == 0 <=> its zig-zag image is 0
     const uint32_t t2 = ZZ ? (uint32_t)del : (((uint32_t)del << 1) ^ (uint32_t)(del >> 31));  // n + zmode = 2|del| - (del < 0)
-    const uint32_t nzf = min(t2, 1u);                                  // del != 0
+    uint32_t nzf;                                                      // del != 0
+    asm("v_min_u32 %0, 1, %1" : "=v"(nzf) : "v"(t2));                  // (one instruction; the compiler prefers compare + select)
     const uint32_t inr = CHECKED ? (valid ? g.inrun : 0u) : g.inrun;
     const uint32_t sw = inr & (nzf ^ 1u);                              // a zero swallowed by the open run
-    g.nz += sw;
-    const uint32_t capf = sw & ((g.nz + 1u) >> 16);                    // the run just reached 65535
-    const uint32_t cl = inr & (nzf | capf);                            // the run ends before / at this residual
-    // (B) a scalar test and branch over the (rare) close; no exec-mask change on the way that skips it
+    g.nz1 += sw;
+    // the run ends before this residual (non-zero) or at it (it just reached 65535 zeros: nz1 = 65536; an open run
+    // never holds more, so the shift is 0 whenever the residual is non-zero)
+    const uint32_t cl = inr & (nzf | (g.nz1 >> 16));
+    // (B) one predicated region for the (rare) close
     if (cl) {
+        const uint32_t capf = sw;  // closed at a zero: the cap
         golf_close_run<WRITE>(g, recip);
         if (capf) g.zmode = 0;
     }
@@ -167,7 +170,7 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
         g.mb = live ? mb : g.mb;
         g.zmode = live ? (enter ? 1u : 0u) : g.zmode;
         g.inrun = live ? (enter ? 1u : 0u) : g.inrun;
-        g.nz = (live && enter) ? 0u : g.nz;
+        g.nz1 = (live && enter) ? 1u : g.nz1;
     }
 }
 
@@ -176,7 +179,7 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
 template <bool WRITE>
 __device__ __forceinline__ void golf_finish(GolF &g, bool active, const uint32_t *recip)
 {
-    const bool close = active && g.inrun && g.nz > 0;
+    const bool close = active && g.inrun && g.nz1 > 1;
     if (__any(close)) {
         if (close) golf_close_run<WRITE>(g, recip);
     }
