@@ -147,3 +147,42 @@ def test_foreign_element_sequences_and_short_packets(gpu_ctx, oracle):
                 assert ns[p] == want_n, (name, p)
                 a = p * f3.packet_bytes
                 assert np.array_equal(out[a:a + want_n * f3.bytes_per_frame], want), (name, p)
+
+
+@pytest.mark.parametrize("channels,depth,frame", [(5, 24, 1000), (3, 16, 52), (7, 32, 4096 * 2), (4, 20, 333)])
+def test_odd_frame_sizes(gpu_ctx, oracle, channels, depth, frame):
+    """frame sizes that are no multiple of the tile / vector widths, incl. packets whose PCM is not 16-byte aligned"""
+    import torch
+    fmt = alac_amd.make_format(frame, depth, channels)
+    n = 9
+    rng = np.random.default_rng(frame + channels)
+    bps = fmt.bytes_per_frame // channels
+    t = np.arange(n * frame)
+    cols = []
+    for c in range(channels):
+        amp = 1 << (depth - 3)
+        x = (amp * np.sin(t * (0.002 + 0.01 * c)) + rng.integers(-amp // 16, amp // 16 + 1, t.size)).astype(np.int64)
+        if depth == 20:
+            x <<= 4
+        b = (x & ((1 << (8 * bps)) - 1)).astype("<u8").view(np.uint8).reshape(-1, 8)[:, :bps]
+        cols.append(b)
+    pcm = np.ascontiguousarray(np.concatenate(cols, axis=1)).reshape(-1)
+    sizes_in = [frame] * n
+    sizes_in[2], sizes_in[8] = max(frame // 3, 1), max(frame - 1, 1)
+    ns = torch.tensor(sizes_in, dtype=torch.int32).cuda()
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, num_samples=ns)
+    enc = oracle.encoder(frame, depth, channels)
+    off = 0
+    for p, N in enumerate(sizes_in):
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + N * fmt.bytes_per_frame], N)
+        assert sizes[p] == len(pk) and np.array_equal(stream[off:off + len(pk)], pk), (p, N)
+        off += len(pk)
+    offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    out, nso, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), n)
+    gpu_ctx.synchronize()
+    assert not st.cpu().numpy().any() and np.array_equal(nso.cpu().numpy(), np.array(sizes_in))
+    out = out.cpu().numpy()
+    for p, N in enumerate(sizes_in):
+        a = p * fmt.packet_bytes
+        assert np.array_equal(out[a:a + N * fmt.bytes_per_frame], pcm[a:a + N * fmt.bytes_per_frame]), p
