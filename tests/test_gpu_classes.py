@@ -20,7 +20,8 @@ def harness(gpu_ctx):
     return os.path.join(CPP, "fork_calls")
 
 
-@pytest.mark.parametrize("bits,ch,frames", [(16, 2, 4096 * 5 + 321), (16, 1, 4096 * 2 + 7), (24, 2, 4096 * 2), (32, 2, 4096 + 100)])
+@pytest.mark.parametrize("bits,ch,frames", [(16, 2, 4096 * 5 + 321), (16, 1, 4096 * 2 + 7), (24, 2, 4096 * 2), (32, 2, 4096 + 100),
+                                             (16, 6, 4096 * 3 + 50), (24, 3, 4096 + 9)])
 def test_reference_call_sequence(harness, oracle, tmp_path, bits, ch, frames):
     pcm = music_like(frames, ch, bits, seed=bits + ch)
     (tmp_path / "in.pcm").write_bytes(pcm)
