@@ -57,6 +57,7 @@ SIGNATURES = {
     "alac_hip_magic_cookie_full": (_u32, [C.POINTER(Format), _u32, _u32, _vp, _u32]),
     "alac_hip_state_int16": (_u32, [C.POINTER(Format)]),
     "alac_hip_decode_workspace_bytes": (_u64, [C.POINTER(Format), _u32]),
+    "alac_hip_decode_workspace_bytes_stream": (_u64, [C.POINTER(Format), _u32, _u64]),
     "alac_hip_decode": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _vp]),
     "alac_hip_format_from_cookie": (_i32, [_vp, _u32, C.POINTER(Format)]),
     "alac_hip_pc_block": (_i32, [_vp, _vp, _vp, _u32, _u32, _i32, _vp, _i32, _u32, _u32]),
@@ -223,7 +224,8 @@ class Context:
         pcm = t.zeros(num_packets * fmt.packet_bytes, dtype=t.uint8, device=self.device)
         ns = t.zeros(num_packets, dtype=t.int32, device=self.device)
         st = t.zeros(num_packets, dtype=t.int32, device=self.device)
-        wsb = int(self.lib.alac_hip_decode_workspace_bytes(C.byref(fmt), num_packets))
+        # sized from the stream actually handed over (ID_FIL / ID_DSE padding may exceed the regular bound)
+        wsb = int(self.lib.alac_hip_decode_workspace_bytes_stream(C.byref(fmt), num_packets, int(stream.numel())))
         ws = self._workspace(wsb)
         rc = self.lib.alac_hip_decode(self.h, ck.ctypes.data, ck.size, stream.data_ptr(), offsets.data_ptr(),
                                       num_packets, ws.data_ptr(), ws.numel(), pcm.data_ptr(), ns.data_ptr(),

@@ -119,7 +119,7 @@ void ALACDecoder::fillWriteBuffer(void *deviceSampleBuffer, uint32_t /*numChanne
     std::vector<uint64_t> offs(np + 1, 0);
     for (uint32_t i = 0; i < np; i++) offs[i + 1] = offs[i] + mQueuedSizes[i];
     alac_hip_format fmt = {mConfig.frameLength, mConfig.bitDepth, mConfig.numChannels, mConfig.sampleRate};
-    const uint64_t wsBytes = alac_hip_decode_workspace_bytes(&fmt, np);
+    const uint64_t wsBytes = alac_hip_decode_workspace_bytes_stream(&fmt, np, offs[np]);
     void *dStream = nullptr, *dOffs = nullptr, *dWs = nullptr, *dNs = nullptr, *dSt = nullptr;
     hipStream_t st = (hipStream_t)alac_hip_stream(mCtx);
     bool ok = hipMalloc(&dStream, offs[np] + 16) == hipSuccess && hipMalloc(&dOffs, (np + 1) * 8ull) == hipSuccess &&
@@ -132,7 +132,22 @@ void ALACDecoder::fillWriteBuffer(void *deviceSampleBuffer, uint32_t /*numChanne
         mLastStatus = alac_hip_decode(mCtx, mCookie.data(), (uint32_t)mCookie.size(), (const uint8_t *)dStream,
                                       (const uint64_t *)dOffs, np, dWs, wsBytes, (uint8_t *)deviceSampleBuffer,
                                       (uint32_t *)dNs, (int32_t *)dSt);
-        if (mLastStatus == ALAC_HIP_noErr && hipStreamSynchronize(st) != hipSuccess) mLastStatus = kALAC_ParamError;
+        if (mLastStatus == ALAC_HIP_noErr && alac_hip_synchronize(mCtx) != ALAC_HIP_noErr) mLastStatus = kALAC_ParamError;
+        // per-packet results: a packet that failed to decode must not pass for audio — its slot in the caller's buffer is
+        // zeroed and the first failure becomes the status of the call (what Decode returned for that packet in the
+        // reference's per-packet loop, convert-utility/main.cu:719-724)
+        if (mLastStatus == ALAC_HIP_noErr) {
+            std::vector<int32_t> stv(np, 0);
+            if (hipMemcpy(stv.data(), dSt, np * 4ull, hipMemcpyDeviceToHost) != hipSuccess) {
+                mLastStatus = kALAC_ParamError;
+            } else {
+                for (uint32_t i = 0; i < np; i++) {
+                    if (stv[i] == 0) continue;
+                    if (mLastStatus == ALAC_HIP_noErr) mLastStatus = stv[i];
+                    (void)hipMemset((uint8_t *)deviceSampleBuffer + (size_t)i * theOutputPacketBytes, 0, (size_t)theOutputPacketBytes);
+                }
+            }
+        }
     } else {
         mLastStatus = kALAC_MemFullError;
     }

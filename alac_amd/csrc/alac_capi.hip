@@ -32,6 +32,10 @@ struct alac_hip_ctx {
     hipStream_t mcStream = nullptr;
     hipEvent_t mcFork = nullptr, mcJoin = nullptr;
     bool mcReady = false;
+    // error word of the in-launch hand-offs (HandoffCtl): pinned host memory the kernels write with a system-scope
+    // store when a consumer's bounded wait runs out; read without a copy after a synchronize
+    uint32_t *errHost = nullptr;
+    uint32_t *errDev = nullptr;
 };
 
 namespace {
@@ -58,6 +62,25 @@ bool format_ok(const alac_hip_format *f)
 }
 
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+HandoffCtl handoff_ctl(const alac_hip_ctx *ctx)
+{
+    HandoffCtl h;
+    h.err = ctx->errDev;
+    const char *v = getenv("ALAC_HIP_DEBUG_LOSE_HANDOFF");  // test switch: producers never publish, consumers give up fast
+    h.lose = (v && v[0] == '1') ? 1u : 0u;
+    h.spinLimit = h.lose ? (1u << 8) : (1u << 22);
+    return h;
+}
+
+// after the stream has been synchronised: did a consumer of an in-launch hand-off give up?
+int32_t check_handoff(alac_hip_ctx *ctx)
+{
+    if (!ctx->errHost || *(volatile uint32_t *)ctx->errHost == 0) return ALAC_HIP_noErr;
+    *(volatile uint32_t *)ctx->errHost = 0;
+    return fail(ctx, ALAC_HIP_MemFullError,
+                "an in-launch producer/consumer hand-off timed out: the results of the calls since the last synchronize are invalid");
+}
 
 struct EncLayout {
     uint64_t recs, bitWords, pred, total;
@@ -208,25 +231,31 @@ struct DecLayout {
     uint32_t maxElems;
 };
 
-DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets)
+// streamBytes = 0: every packet at its largest regular size (what an encoder of this library or Apple's can emit);
+// a stream padded with ID_FIL / ID_DSE elements may be longer, and a caller who knows its length passes it
+DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets, uint64_t streamBytes = 0)
 {
     DecLayout L;
     uint64_t off = 0;
     L.recs = off;
-    L.maxElems = f->num_channels > 2 ? f->num_channels : 1;
+    // a mono / stereo stream may still be a sequence of SCE / LFE elements (codec/ALACDecoder.cu:622-756): the lane
+    // decoder keeps one record per channel
+    L.maxElems = f->num_channels;
     off = align_up(off + (uint64_t)numPackets * L.maxElems * sizeof(DecRec), 256);
     L.resid = off;
     off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
-    // the stream re-staged as MSB-first words, zero padded (alac_decode_v1.hip): every packet at its largest
-    L.words = off;
-    L.capWords = ((uint64_t)numPackets * max_output_bytes(f, 1) + 3) / 4 + 64;
-    off = align_up(off + L.capWords * 4, 256);
     L.prog = off;
     off = align_up(off + (uint64_t)numPackets * 8, 256);
     L.elemBit = off;
     off = align_up(off + (uint64_t)numPackets * 4, 256);
     L.mismatch = off;
     off = align_up(off + 4, 256);
+    // LAST: the stream re-staged as MSB-first words + 64 zero words (alac_decode_v1.hip).  Whatever the caller's
+    // workspace holds beyond this offset is used, so a longer stream only needs a larger workspace.
+    L.words = off;
+    const uint64_t regular = (uint64_t)numPackets * max_output_bytes(f, 1);
+    L.capWords = ((streamBytes > regular ? streamBytes : regular) + 3) / 4 + 64;
+    off = align_up(off + L.capWords * 4, 256);
     L.total = off;
     return L;
 }
@@ -282,6 +311,12 @@ int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream)
         }
         c->ownStream = true;
     }
+    if (hipHostMalloc((void **)&c->errHost, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->errDev, c->errHost, 0) != hipSuccess) {
+        alac_hip_destroy(c);
+        return ALAC_HIP_MemFullError;
+    }
+    *c->errHost = 0;
     *out_ctx = c;
     return ALAC_HIP_noErr;
 }
@@ -313,6 +348,7 @@ void alac_hip_destroy(alac_hip_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    if (ctx->errHost) (void)hipHostFree(ctx->errHost);
     delete ctx;
 }
 
@@ -321,7 +357,7 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx)
     if (!ctx) return ALAC_HIP_ParamError;
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
-    return ALAC_HIP_noErr;
+    return check_handoff(ctx);
 }
 
 const char *alac_hip_last_error(const alac_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -558,6 +594,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
         vb.cost2 = (uint32_t *)(ws + L.cost2);
         vb.flags = (uint32_t *)(ws + L.flags);
         vb.chainsPad = L.chainsPad;
+        vb.ho = handoff_ctl(ctx);
         e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, ctx->vs, num_packets, maxSeg, ctx->stream, ev);
     }
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "encode launch", e);
@@ -708,6 +745,12 @@ uint64_t alac_hip_decode_workspace_bytes(const alac_hip_format *fmt, uint32_t nu
     return dec_layout(fmt, num_packets).total;
 }
 
+uint64_t alac_hip_decode_workspace_bytes_stream(const alac_hip_format *fmt, uint32_t num_packets, uint64_t stream_bytes)
+{
+    if (!format_ok(fmt)) return 0;
+    return dec_layout(fmt, num_packets, stream_bytes).total;
+}
+
 int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t cookie_size, const uint8_t *d_stream,
                         const uint64_t *d_packet_offsets, uint32_t num_packets, void *d_workspace,
                         uint64_t workspace_bytes, uint8_t *d_pcm_out, uint32_t *d_num_samples_out,
@@ -723,8 +766,9 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
         return fail(ctx, ALAC_HIP_ParamError, "null buffer");
     if (((uintptr_t)d_workspace & 255) || ((uintptr_t)d_pcm_out & 3))
         return fail(ctx, ALAC_HIP_ParamError, "misaligned buffer");
-    const DecLayout L = dec_layout(&fmt, num_packets);
+    DecLayout L = dec_layout(&fmt, num_packets);
     if (workspace_bytes < L.total) return fail(ctx, ALAC_HIP_ParamError, "workspace too small");
+    L.capWords = (workspace_bytes - L.words) / 4;  // all of it: packets that do not fit the staged words get status -50
     // skip wrappers again to reach pb/mb/kb
     const uint8_t *ck = h_cookie;
     uint32_t size = cookie_size;
@@ -742,12 +786,16 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.pb = ck[6];
     da.mb = ck[7];
     da.kb = ck[8];
+    // the kernels shift by kb and divide by what pb scales: a cookie outside what dyn_decomp accepts
+    // (codec/ag_dec.c:282-286 rejects kb / bit widths it cannot code) is a parameter error, not undefined shifts
+    if (da.kb < 1 || da.kb > 16 || da.pb == 0) return fail(ctx, ALAC_HIP_ParamError, "bad AG parameters in cookie (pb / kb)");
     da.maxElems = L.maxElems;
     da.recs = (DecRec *)(ws + L.recs);
     da.resid = (int32_t *)(ws + L.resid);
     da.pcmOut = d_pcm_out;
     da.numSamplesOut = d_num_samples_out;
     da.statusOut = d_status;
+    da.ho = handoff_ctl(ctx);
     hipError_t e;
     if (use_lane_decoder()) {
         e = launch_decode(da, ctx->stream);
@@ -765,6 +813,15 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
         if (e == hipSuccess && mismatch) e = launch_decode(da, ctx->stream);
     } else {
         e = launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream);
+        // A mono / stereo stream whose packets carry another element sequence (two SCEs for two channels, fill in
+        // front of ...: status -4 from the fast pipeline) is decoded again by the lane decoder, which follows whatever
+        // the packets carry.  No host round trip: its kernels are gated on the device-side count of such packets.
+        if (e == hipSuccess) e = launch_count_status(da.statusOut, num_packets, -4, (uint32_t *)(ws + L.mismatch), ctx->stream);
+        if (e == hipSuccess) {
+            DecodeArgs dg = da;
+            dg.gate = (const uint32_t *)(ws + L.mismatch);
+            e = launch_decode(dg, ctx->stream);
+        }
     }
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "decode launch", e);
     return ALAC_HIP_noErr;
@@ -880,6 +937,7 @@ int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *
         if ((e = hipMemcpyAsync(h_state, dState.p, stateBytes, hipMemcpyDeviceToHost, st)))
             return fail(ctx, ALAC_HIP_ParamError, "D2H state", e);
     if ((e = hipStreamSynchronize(st))) return fail(ctx, ALAC_HIP_ParamError, "sync", e);
+    if (int32_t hrc = check_handoff(ctx)) return hrc;
     if (out_total_bytes) *out_total_bytes = total;
     return ALAC_HIP_noErr;
 }
@@ -935,7 +993,7 @@ int32_t alac_hip_decode_host(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_
     const uint64_t total = offs[num_packets];
     const uint32_t bpf = fmt.num_channels * bytes_per_sample(fmt.bit_depth);
     const uint64_t pcmBytes = (uint64_t)num_packets * fmt.frame_size * bpf;
-    const uint64_t wsBytes = alac_hip_decode_workspace_bytes(&fmt, num_packets);
+    const uint64_t wsBytes = alac_hip_decode_workspace_bytes_stream(&fmt, num_packets, total);
     DevBuf dStream, dOffs, dWs, dPcm, dNs, dSt;
     hipError_t e;
     if ((e = dStream.alloc(total + 16)) || (e = dOffs.alloc((num_packets + 1) * 8ull)) || (e = dWs.alloc(wsBytes)) ||
@@ -955,7 +1013,7 @@ int32_t alac_hip_decode_host(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_
         (e = hipMemcpyAsync(h_status, dSt.p, num_packets * 4ull, hipMemcpyDeviceToHost, st)) ||
         (e = hipStreamSynchronize(st)))
         return fail(ctx, ALAC_HIP_ParamError, "decode execution", e);
-    return ALAC_HIP_noErr;
+    return check_handoff(ctx);
 }
 
 }  // extern "C"

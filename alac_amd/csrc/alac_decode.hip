@@ -109,6 +109,7 @@ __device__ __forceinline__ int32_t decomp_lane(const uint8_t *base, uint64_t nby
 
 __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
 {
+    if (A.gate && *A.gate == 0) return;
     const uint32_t p = blockIdx.x * 64u + threadIdx.x;
     if (p >= A.numPackets) return;
     const uint64_t off = A.offsets[p];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
         case 3:    // ID_LFE
         case 1: {  // ID_CPE
             const uint32_t ech = (tag == 1) ? 2u : 1u;
-            if (channelIndex + ech > A.numChannels) {  // :760-762 (a pair that does not fit ends the packet)
+            if (channelIndex + ech > A.numChannels || elem >= A.maxElems) {  // :760-762 (a pair that does not fit ends the packet)
                 done = true;
                 break;
             }
@@ -258,6 +259,7 @@ __device__ __forceinline__ const DecRec *element_of(const DecodeArgs &A, uint32_
 
 __global__ __launch_bounds__(64) void k_decode_unpc(DecodeArgs A)
 {
+    if (A.gate && *A.gate == 0) return;
     const uint64_t gid = (uint64_t)blockIdx.x * 64u + threadIdx.x;
     if (gid >= (uint64_t)A.numPackets * A.numChannels) return;
     const uint32_t ch = (uint32_t)(gid / A.numPackets);
@@ -293,6 +295,7 @@ __device__ __forceinline__ void store_sample(uint8_t *p, int32_t x)
 template <int DEPTH, int CH>
 __global__ __launch_bounds__(256) void k_decode_unmix(DecodeArgs A)
 {
+    if (A.gate && *A.gate == 0) return;
     __shared__ int32_t tu[64][65];
     __shared__ int32_t tv[CH == 2 ? 64 : 1][65];
     const uint32_t tileP = blockIdx.x * 64u, tileJ = blockIdx.y * 64u;
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void k_decode_unmix(DecodeArgs A)
 template <int DEPTH>
 __global__ __launch_bounds__(256) void k_decode_unmix_mc(DecodeArgs A)
 {
+    if (A.gate && *A.gate == 0) return;
     __shared__ int32_t tu[64][65];
     __shared__ int32_t tv[64][65];
     const uint32_t tileP = blockIdx.x * 64u, tileJ = blockIdx.y * 64u;
@@ -411,10 +415,10 @@ template <int DEPTH>
 static void launch_unmix_depth(const DecodeArgs &da, hipStream_t st)
 {
     dim3 grid((da.numPackets + 63) / 64, (da.frameSize + 63) / 64);
-    if (da.numChannels > 2)
+    // two channels may arrive as one CPE or as two SCE / LFE elements (codec/ALACDecoder.cu:622-756): the per-element
+    // kernel follows the records, k_decode_unmix<., 2> would take the packet for one pair
+    if (da.numChannels >= 2)
         hipLaunchKernelGGL((k_decode_unmix_mc<DEPTH>), grid, dim3(256), 0, st, da);
-    else if (da.numChannels == 2)
-        hipLaunchKernelGGL((k_decode_unmix<DEPTH, 2>), grid, dim3(256), 0, st, da);
     else
         hipLaunchKernelGGL((k_decode_unmix<DEPTH, 1>), grid, dim3(256), 0, st, da);
 }

@@ -237,6 +237,16 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         }
     }
 
+    if (live && status == 0) {
+        // Untrusted input: (1) every byte of the packet must be inside the staged word stream — a stream longer than the
+        // workspace was sized for (legal ID_FIL / ID_DSE padding can exceed alac_hip_decode_workspace_bytes' bound) is
+        // truncated by k_dec_stage, so its tail packets fail here instead of decoding bytes that are not theirs;
+        // (2) an uncompressed element's fixed-width payload must end inside the packet (the reference's overrun test,
+        // codec/ALACDecoder.cu:996-1000, returns kALAC_ParamError for the same packet).
+        const uint64_t stagedBytes = (V.capWords - 64) * 4;  // k_dec_stage keeps 64 zero words behind what it copies
+        if (off + nbytes > stagedBytes) status = -50;
+        if (haveElement && R.escape && hpos + (uint64_t)R.numSamples * R.elementChannels * A.bitDepth > nbytes * 8) status = -50;
+    }
     if (live) {
         rec->numSamples = R.numSamples;
         rec->escape = R.escape;
@@ -270,11 +280,12 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
     const uint64_t off = A.offsets[p];
     const uint64_t bitBase = (off & 3) * 8 + rec->pad;
     const uint32_t *words = V.words + (off >> 2);
+    const uint64_t lastWord = V.capWords - 2 - (off >> 2);  // k_dec_header has checked the payload; never index past the stage
     int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
     for (uint32_t j = first; j < n; j += step) {
         for (uint32_t c = 0; c < ech; c++) {
             const uint64_t b = bitBase + ((uint64_t)j * ech + c) * w;
-            const uint32_t i = (uint32_t)(b >> 5), sh = (uint32_t)(b & 31);
+            const uint32_t i = (uint32_t)min((uint64_t)(b >> 5), lastWord), sh = (uint32_t)(b & 31);
             const uint64_t two = ((uint64_t)words[i] << 32) | words[i + 1];
             const uint32_t v = (uint32_t)((two << sh) >> 32) >> (32 - w);
             (rowU + c * A.frameSize)[j] = (int32_t)(v << (32 - w)) >> (32 - w);
@@ -345,7 +356,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
             const uint32_t all = 0xffffffffu;
             const uint32_t u = (!E.active || E.chan > 0) ? all : E.c;
             const uint32_t v = !E.active ? all : (E.chan > 0 ? E.c : 0u);
-            if (prog) {
+            if (prog && !A.ho.lose) {
                 __hip_atomic_store(prog, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(prog + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -603,13 +614,24 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
         if constexpr (FOLLOW) {
             if (availMin >= rows) return;
             const uint32_t want = active ? min(rows, n) : 0u;
-            for (uint32_t spins = 0; spins < (1u << 22); spins++) {
-                const uint32_t a = active ? __hip_atomic_load(progPtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            bool seen = false;
+            uint32_t a = 0;
+            for (uint32_t spins = 0; spins < A.ho.spinLimit; spins++) {
+                a = active ? __hip_atomic_load(progPtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
                 if (__all(a >= want)) {
                     availMin = wave_min_dec(a);
+                    seen = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);
+            }
+            if (!seen) {
+                // the entropy lanes never published these rows: what is in the plane is not this packet's residuals.
+                // The packets concerned fail (kALAC_ParamError), the context's error word makes the call fail, and the
+                // wave stops waiting so that the launch drains.
+                if (active && a < want) A.statusOut[p] = -50;
+                if (A.ho.err && lane == 0) __hip_atomic_store(A.ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                availMin = 0xffffffffu;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -840,6 +862,13 @@ __global__ void k_dec_count_status(const int32_t *status, uint32_t n, int32_t co
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && status[i] == code) atomicAdd(count, 1u);
+}
+
+hipError_t launch_count_status(const int32_t *status, uint32_t n, int32_t code, uint32_t *count, hipStream_t st)
+{
+    (void)hipMemsetAsync(count, 0, 4, st);
+    hipLaunchKernelGGL(k_dec_count_status, dim3((n + 255) / 256), dim3(256), 0, st, status, n, code, count);
+    return hipGetLastError();
 }
 
 hipError_t launch_decode_v1_elements(const DecodeArgs &da, const McElement *el, uint32_t numElements, uint32_t *words,

@@ -88,8 +88,9 @@ __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 // release to write back, and the flag can follow directly.  Measured: an agent-scope release fence here
 // (buffer_wbl2 of the WHOLE L2, which also holds the coder waves' dirty bit words) costs ~11 us per
 // publish; ALAC_HIP_PUBFENCE=1 puts it back (and publishes every 4 tiles instead of every tile).
-__device__ __forceinline__ void publish_rows(uint32_t *flag, uint32_t rows, int lane, bool fence)
+__device__ __forceinline__ void publish_rows(uint32_t *flag, uint32_t rows, int lane, bool fence, uint32_t lose = 0)
 {
+    if (lose) return;  // ALAC_HIP_DEBUG_LOSE_HANDOFF: the consumers must notice
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (fence) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -99,20 +100,32 @@ __device__ __forceinline__ void publish_rows(uint32_t *flag, uint32_t rows, int 
 }
 
 // Consumer: relaxed poll of the (two) producer words, then ONE agent-scope acquire before any newly
-// published row is loaded.  Bounded spin: a lost producer yields wrong packets (caught by parity), not a hang.
+// published row is loaded.  The spin is bounded; a consumer that gives up has NOT seen its rows: it raises the
+// context's error word (host-mapped, checked at the next synchronize -> the call fails with kALAC_MemFullError) and
+// carries on with whatever is there, so the launch still drains.
+// Forward progress: producers are the workgroups [0, nLms) of the launch and never wait for anything, so each of them
+// finishes in bounded time once it is resident; a consumer only ever waits for producers.  The dispatcher hands out
+// workgroups in id order in practice (producers first), but nothing here DEPENDS on that: if consumers were resident
+// first they would hold at most their own SIMD slots while spinning with s_sleep, producers fill the remaining slots
+// or follow as consumers time out — the outcome is then an error, never a hang and never silent corruption.
 struct RowWait {
     const uint32_t *f0, *f1;
     uint32_t avail, base;
+    HandoffCtl ho;
     __device__ __forceinline__ void operator()(uint32_t rows)
     {
         rows += base;
         if (avail >= rows) return;
-        for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+        for (uint32_t spins = 0; spins < ho.spinLimit; spins++) {
             const uint32_t a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t b = f1 ? __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
             avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a < b ? a : b));
             if (avail >= rows) break;
             __builtin_amdgcn_s_sleep(16);
+        }
+        if (avail < rows) {
+            if (ho.err && threadIdx.x == 0) __hip_atomic_store(ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            avail = 0xffffffffu;  // stop polling: the call is already lost
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -135,6 +148,7 @@ struct V1Args {
     uint32_t *flags;       // producer progress words of the fused final kernel (zeroed per call)
     uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
     uint32_t idleFast;     // 1: lanes without work do not force the checked paths (latency regime, see launcher)
+    HandoffCtl ho;         // error word / spin bound / test switch of the in-launch hand-offs
 };
 
 // ================================================================================================
@@ -557,7 +571,7 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 }
             }
             // fused final kernel: tell the coder waves how many residual rows are complete (every 4 tiles)
-            if (flag && ((((j0 / kTile) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + kTile, (int)runTo), lane, (A.pubMask >> 31) != 0);
+            if (flag && ((((j0 / kTile) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + kTile, (int)runTo), lane, (A.pubMask >> 31) != 0, A.ho.lose);
         }
         lds_order();
         if (fastNext) stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
@@ -747,7 +761,7 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
                                         lane, flag, (uint32_t)r << 16, &head, r == 0 ? 1 : 2);
         }
         store_row<2>(J, a, lane);
-        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);
+        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);
     } else {
         gol_table_init(recip, lane);
         __syncthreads();
@@ -766,6 +780,7 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = r << 16;
+        wait.ho = A.ho;
         golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, one_plane(plane, stride, chain), wait);
         if (active) A.bits1[t] = g.bits;
     }
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         uint32_t *flag = A.flags + blockIdx.x;
         lms_pass<DEPTH, CH, 2, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
         store_row<2>(J, a, lane);
-        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0);  // nothing more will come (also covers inactive waves)
+        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come (also covers inactive waves)
     } else {
         gol_table_init(recip, lane);
         __syncthreads();
@@ -948,6 +963,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = 0;
+        wait.ho = A.ho;
         golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
         golf_flush<true>(g);
         if (active) rec->c[c].bits = g.bits;
@@ -1116,6 +1132,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;
+    A.ho = vb.ho;
     {
         static const uint32_t pm = [] {
             const char *v = getenv("ALAC_HIP_PUBFENCE");

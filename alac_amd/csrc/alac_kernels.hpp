@@ -71,7 +71,18 @@ void launch_scan_pack(uint32_t depth, uint32_t channels, uint32_t *packetBytes, 
                       uint32_t numPackets, hipStream_t st, hipEvent_t *ev, bool recordScan = true);
 
 // tap-parallel pipeline (alac_encode_v1.hip)
+// In-launch producer -> consumer hand-offs (alac_encode_v1.hip RowWait, alac_decode_v1.hip k_dec_fused): a consumer
+// whose bounded spin runs out has NOT seen its rows.  It raises *err (a host-mapped word the context checks at the next
+// synchronize: the call then fails with kALAC_MemFullError instead of returning corrupt packets) and, in the decoder,
+// marks its packets kALAC_ParamError.  `lose` is the test switch ALAC_HIP_DEBUG_LOSE_HANDOFF=1: producers never publish.
+struct HandoffCtl {
+    uint32_t *err = nullptr;
+    uint32_t spinLimit = 1u << 22;
+    uint32_t lose = 0;
+};
+
 struct V1Buffers {
+    HandoffCtl ho;
     int16_t *state;        // [segments][64] working coefficient rows (caller's d_state or workspace)
     bool stateInitialised; // rows already hold the caller's initial state
     int32_t *resA, *resB, *resC;
@@ -120,8 +131,10 @@ struct DecodeArgs {
     uint32_t numPackets;
     uint32_t frameSize, bitDepth, numChannels;
     uint32_t mb, pb, kb;
-    uint32_t maxElems;  // element records per packet: 1 for <= 2 channels, numChannels above (lane decoder only)
+    uint32_t maxElems;  // element records per packet (lane decoder): numChannels, a stream may be all SCE / LFE elements
     DecRec *recs;       // [maxElems][numPackets]
+    const uint32_t *gate = nullptr;  // lane decoder as a fallback: its kernels do nothing unless *gate != 0
+    HandoffCtl ho;
     int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
     uint8_t *pcmOut;
     uint32_t *numSamplesOut;
@@ -164,6 +177,9 @@ void launch_mc_tables(const uint32_t *numSamples, uint32_t numPackets, const uin
 // sizes + exclusive scan + bit-granular concatenation of the element packets
 void launch_mc_splice(const McSpliceArgs &a, hipStream_t st);
 void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st);
+
+// *count (device) = number of packets whose status is `code`
+hipError_t launch_count_status(const int32_t *status, uint32_t n, int32_t code, uint32_t *count, hipStream_t st);
 
 // a stream of 3..8 channels on the second-generation decoder: one pass per element of the channel count's element
 // sequence, element r of every packet decoded as the mono / stereo packet that starts where element r - 1 ended

@@ -160,6 +160,15 @@ bool decode_group(std::vector<Job *> &jobs, const std::vector<alacfile::AlacCafC
         return false;
     }
     const uint32_t ch = dec.mConfig.numChannels, bits = dec.mConfig.bitDepth, frame = dec.mConfig.frameLength;
+    // The library writes 3 bytes per 20-bit sample; this tool (like the reference, main.cu:389) sizes PCM as bits / 8.
+    // The 'desc' flag was checked by the caller, but the COOKIE decides what the decoder writes: refuse a cookie
+    // whose depth this tool cannot size (20) or that contradicts the file's description.
+    for (size_t j = 0; j < jobs.size(); j++) {
+        if (bits == 20 || !(bits == 16 || bits == 24 || bits == 32) || source_bits(jobs[j]->info.alacSourceFlag) != bits) {
+            fprintf(stderr, " Magic cookie bit depth %u does not match the file description: \"%s\"\n", bits, jobs[j]->in.c_str());
+            return false;
+        }
+    }
     const uint32_t bytesPerFrame = ch * (bits >> 3);
     std::vector<uint32_t> sizes, firstPacket;
     Bytes stream;

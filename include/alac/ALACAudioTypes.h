@@ -9,12 +9,16 @@
 #define ALAC_AMD_AUDIOTYPES_H
 
 #include <stdint.h>
+#include "ALACBitUtilities.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
+#ifndef ALAC_AMD_NOERR_DEFINED
+#define ALAC_AMD_NOERR_DEFINED
 enum { ALAC_noErr = 0 };
+#endif
 enum {
     kALAC_UnimplementedError = -4,
     kALAC_FileNotFoundError = -43,
@@ -71,22 +75,6 @@ typedef struct ALACSpecificConfig {
     uint32_t sampleRate;
 } ALACSpecificConfig;
 #pragma pack(pop)
-
-typedef struct BitBuffer {
-    uint8_t *cur;
-    uint8_t *end;
-    uint32_t bitIndex;
-    uint32_t byteSize;
-} BitBuffer;
-
-/* codec/ALACBitUtilities.c:32-38 */
-static inline void BitBufferInit(BitBuffer *bits, uint8_t *buffer, uint32_t byteSize)
-{
-    bits->cur = buffer;
-    bits->end = buffer + byteSize;
-    bits->bitIndex = 0;
-    bits->byteSize = byteSize;
-}
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,10 @@ int32_t alac_hip_device_count(void);
 int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream);
 void alac_hip_destroy(alac_hip_ctx *ctx);
 /* Block until everything enqueued on the context's stream has completed
- * (the cudaDeviceSynchronize of codec/ALACEncoder.cu:1448). */
+ * (the cudaDeviceSynchronize of codec/ALACEncoder.cu:1448).  Returns kALAC_MemFullError if, in any call since the last
+ * synchronize, a consumer wave of an in-launch producer/consumer hand-off gave up waiting (a preempted or lost producer):
+ * the outputs of those calls are then invalid (the decoder also marks the packets concerned kALAC_ParamError).  The
+ * host-buffer entry points below return the same code themselves. */
 int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
 /* Text of the last HIP/parameter error on this context ("" if none). */
 const char *alac_hip_last_error(const alac_hip_ctx *ctx);
@@ -130,6 +133,11 @@ uint32_t alac_hip_magic_cookie_full(const alac_hip_format *fmt, uint32_t max_fra
  *  codec/dp_dec.c:55, gpu_unmixNN codec/ALACDecoder.cu:193-383). */
 
 uint64_t alac_hip_decode_workspace_bytes(const alac_hip_format *fmt, uint32_t num_packets);
+/* The same for a stream of known length: packets padded with ID_FIL / ID_DSE elements (which the decoder skips,
+ * codec/ALACDecoder.cu:1012-1059) can make a legal stream longer than num_packets regular packets.  alac_hip_decode
+ * uses all of the workspace it is given; packets that still do not fit get status kALAC_ParamError. */
+uint64_t alac_hip_decode_workspace_bytes_stream(const alac_hip_format *fmt, uint32_t num_packets,
+                                                uint64_t stream_bytes);
 
 /*
  * Decode num_packets packets (independent: coefficients travel in each packet header).

@@ -26,6 +26,25 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/alac_hip.h but not exported"
 
 
+def test_library_exports_the_reference_stage_surface():
+    """SURVEY.md §8b "C stage ABI": every prototype of include/alac/{matrixlib,dplib,aglib,ALACBitUtilities}.h — the
+    reference's codec/matrixlib.h:41-60, dplib.h:49-55, aglib.h:70-74, ALACBitUtilities.h:85-97 — is an exported symbol."""
+    lib = ctypes.CDLL(alac_amd.LIB_PATH)
+    want = {"matrixlib.h": ["mix16", "mix20", "mix24", "mix32", "copy20ToPredictor"],
+            "dplib.h": ["init_coefs", "copy_coefs", "pc_block", "unpc_block"],
+            "aglib.h": ["set_standard_ag_params", "set_ag_params", "dyn_comp", "dyn_decomp"],
+            "ALACBitUtilities.h": ["BitBufferInit", "BitBufferRead", "BitBufferReadSmall", "BitBufferReadOne", "BitBufferPeek",
+                                   "BitBufferPeekOne", "BitBufferUnpackBERSize", "BitBufferGetPosition", "BitBufferByteAlign",
+                                   "BitBufferAdvance", "BitBufferRewind", "BitBufferWrite", "BitBufferReset"]}
+    for header, names in want.items():
+        with open(os.path.join(ROOT, "include", "alac", header)) as f:
+            text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+        declared = set(re.findall(r"\b([A-Za-z_]\w*)\s*\(", text))
+        for n in names:
+            assert n in declared, f"{n} not declared in include/alac/{header}"
+            assert hasattr(lib, n), f"{n} declared in include/alac/{header} but not exported"
+
+
 def test_binding_table_matches_header():
     assert sorted(alac_amd.SIGNATURES) == _declared()
     alac_amd.load_library()

@@ -75,3 +75,176 @@ def test_more_packets_than_a_grid_dimension(gpu_ctx, oracle, frame):
     gpu_ctx.synchronize()
     assert int(st.abs().sum()) == 0 and int((ns != frame).sum()) == 0
     assert torch.equal(out, d_pcm)
+
+
+def _bits(value, width):
+    return [(value >> (width - 1 - i)) & 1 for i in range(width)]
+
+
+def _fil(count):
+    """ID_FIL element with `count` payload bytes (codec/ALACDecoder.cu:1012-1027)"""
+    b = _bits(6, 3)
+    if count < 15:
+        b += _bits(count, 4)
+    else:
+        b += _bits(15, 4) + _bits(count - 15 + 1, 8)
+    return b + [1, 0] * (4 * count)
+
+
+def _dse(count, align):
+    """ID_DSE element (codec/ALACDecoder.cu:1033-1059); the caller pads to a byte boundary itself when align is set"""
+    b = _bits(4, 3) + _bits(2, 4) + [align]
+    b += _bits(count, 8) if count < 255 else _bits(255, 8) + _bits(count - 255, 8)
+    return b
+
+
+def _element_bits(pk):
+    b = np.unpackbits(np.ascontiguousarray(pk, np.uint8))
+    last = int(np.nonzero(b)[0][-1])
+    return list(b[:last - 2])  # without ID_END and the padding
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_fill_and_data_elements_are_skipped_and_may_exceed_the_regular_stream_bound(gpu_ctx, oracle, channels):
+    """a legal stream padded with ID_FIL / ID_DSE elements is longer than num_packets regular packets; the
+    workspace is sized from the real stream and every packet decodes (oracle decoder = restated ALACDecoder::Decode)"""
+    import torch
+    depth, n = 16, 6
+    fmt = alac_amd.make_format(4096, depth, channels)
+    pcm = alac_amd.synth_pcm(1, n, fmt)  # packet 0 is full-scale noise: an escape packet, the largest there is
+    enc = oracle.encoder(4096, depth, channels)
+    cookie = enc.cookie()
+    dec = oracle.decoder(cookie)
+    pks = []
+    for p in range(n):
+        enc.reset()
+        e = _element_bits(enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], 4096))
+        if p % 3 == 0:
+            b = _fil(270) + e
+        elif p % 3 == 1:
+            head = _dse(300, 1)
+            head += [0] * (-len(head) % 8) + [1, 1, 0, 0] * (2 * 300)
+            b = _fil(3) + head + e
+        else:
+            b = _dse(7, 0) + [0, 1] * (4 * 7) + e
+        pks.append(np.packbits(np.array(b + [1, 1, 1], np.uint8)))
+    regular = alac_amd.load_library().alac_hip_encode_max_output_bytes(fmt, 1)
+    assert max(len(q) for q in pks) > regular  # the case the fixed bound did not cover
+    stream = np.concatenate(pks)
+    offs = np.concatenate([[0], np.cumsum([len(q) for q in pks])]).astype(np.int64)
+    out, ns, st, _ = gpu_ctx.decode(cookie, torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), n)
+    gpu_ctx.synchronize()
+    out = out.cpu().numpy()
+    for p in range(n):
+        want_st, want, want_n = dec.decode_packet(pks[p], fmt.bytes_per_frame)
+        assert want_st == 0 and want_n == 4096
+        assert int(st[p]) == 0 and int(ns[p]) == 4096, p
+        a = p * fmt.packet_bytes
+        assert np.array_equal(out[a:a + fmt.packet_bytes], want), p
+        assert np.array_equal(want, pcm[a:a + fmt.packet_bytes]), p
+
+
+def test_stream_beyond_the_workspace_fails_cleanly(gpu_ctx, oracle):
+    """the decoder handed a workspace sized for regular packets only: the padded tail packets get -50, nothing is read
+    out of bounds, the packets that fit still decode"""
+    import ctypes as C
+    import torch
+    fmt = alac_amd.make_format(256, 16, 2)
+    n = 8
+    pcm = alac_amd.synth_pcm(1, n, fmt)
+    enc = oracle.encoder(256, 16, 2)
+    pks = []
+    for p in range(n):
+        enc.reset()
+        e = _element_bits(enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], 256))
+        pks.append(np.packbits(np.array(_fil(269) + _fil(269) + _fil(269) + _fil(269) + e + [1, 1, 1], np.uint8)))
+    stream = torch.from_numpy(np.concatenate(pks)).cuda()
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum([len(q) for q in pks])]).astype(np.int64)).cuda()
+    lib = gpu_ctx.lib
+    ck = np.ascontiguousarray(enc.cookie(), np.uint8)
+    wsb = int(lib.alac_hip_decode_workspace_bytes(C.byref(fmt), n))  # NOT the stream-sized variant
+    assert int(lib.alac_hip_decode_workspace_bytes_stream(C.byref(fmt), n, int(stream.numel()))) > wsb
+    ws = torch.zeros(wsb, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(n * fmt.packet_bytes, dtype=torch.uint8, device="cuda")
+    ns = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rc = lib.alac_hip_decode(gpu_ctx.h, ck.ctypes.data, ck.size, stream.data_ptr(), offs.data_ptr(), n, ws.data_ptr(), wsb,
+                             out.data_ptr(), ns.data_ptr(), st.data_ptr())
+    assert rc == 0
+    gpu_ctx.synchronize()
+    st = st.cpu().tolist()
+    assert st[0] == 0 and st[-1] == -50 and all(s in (0, -50) for s in st)
+    assert st == sorted(st, reverse=True)  # a prefix decodes, the tail fails
+    k = st.index(-50)
+    assert np.array_equal(out[:k * fmt.packet_bytes].cpu().numpy(), pcm[:k * fmt.packet_bytes])
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_truncated_escape_packet(gpu_ctx, oracle, channels):
+    """an uncompressed element whose fixed-width payload runs past the packet must not decode the next packet's bytes"""
+    import torch
+    fmt = alac_amd.make_format(4096, 16, channels)
+    pcm = alac_amd.synth_pcm(1, 3, fmt)  # frame 1 = full-scale noise -> escape
+    enc = oracle.encoder(4096, 16, channels)
+    esc = enc.encode_packet(pcm[:fmt.packet_bytes], 4096)
+    assert enc.last_info()["escape"] == 1
+    enc.reset()
+    ok = enc.encode_packet(pcm[2 * fmt.packet_bytes:3 * fmt.packet_bytes], 4096)
+    cut = esc[:len(esc) - 100]
+    pks = [cut, ok, esc]
+    stream = np.concatenate(pks)
+    offs = np.concatenate([[0], np.cumsum([len(q) for q in pks])]).astype(np.int64)
+    out, ns, st, _ = gpu_ctx.decode(enc.cookie(), torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), 3)
+    gpu_ctx.synchronize()
+    assert st.cpu().tolist() == [-50, 0, 0]
+    out = out.cpu().numpy()
+    assert np.array_equal(out[fmt.packet_bytes:2 * fmt.packet_bytes], pcm[2 * fmt.packet_bytes:3 * fmt.packet_bytes])
+    assert np.array_equal(out[2 * fmt.packet_bytes:], pcm[:fmt.packet_bytes])
+
+
+def test_two_channel_stream_of_two_mono_elements(gpu_ctx, oracle):
+    """a 2-channel cookie whose packets are SCE + SCE (or LFE) instead of one CPE is legal
+    (codec/ALACDecoder.cu:622-756); the fast pipeline reports -4 and the gated lane decoder takes the batch"""
+    import torch
+    from oracle_lib import splice_elements, interleave_channels
+    depth, n = 16, 5
+    f1, f2 = alac_amd.make_format(4096, depth, 1), alac_amd.make_format(4096, depth, 2)
+    a, b = alac_amd.synth_pcm(3, n, f1), alac_amd.synth_pcm(13, n, f1)
+    stereo = alac_amd.synth_pcm(4, n, f2)
+
+    def packets(pcm, ch):
+        enc = oracle.encoder(4096, depth, ch)
+        s, z = enc.encode_stream(pcm, n * 4096, 1)
+        o = np.concatenate([[0], np.cumsum(z)]).astype(np.int64)
+        return [s[o[p]:o[p + 1]] for p in range(n)]
+
+    pa, pb, ps = packets(a, 1), packets(b, 1), packets(stereo, 2)
+    cookie = oracle.encoder(4096, depth, 2).cookie()
+    dec = oracle.decoder(cookie)
+    pks = [splice_elements([(pa[p], 0), (pb[p], 1)]) if p != 2 else ps[p] for p in range(n)]  # one ordinary CPE packet among them
+    stream = np.concatenate(pks)
+    offs = np.concatenate([[0], np.cumsum([len(q) for q in pks])]).astype(np.int64)
+    out, ns, st, _ = gpu_ctx.decode(cookie, torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), n)
+    gpu_ctx.synchronize()
+    out = out.cpu().numpy()
+    both = interleave_channels([(a, 1), (b, 1)], depth)
+    for p in range(n):
+        want_st, want, want_n = dec.decode_packet(pks[p], f2.bytes_per_frame)
+        assert want_st == 0 and want_n == 4096
+        assert int(st[p]) == 0 and int(ns[p]) == 4096, p
+        s = slice(p * f2.packet_bytes, (p + 1) * f2.packet_bytes)
+        assert np.array_equal(out[s], want), p
+        assert np.array_equal(want, stereo[s] if p == 2 else both[s]), p
+
+
+def test_cookie_with_unusable_ag_parameters_is_refused(gpu_ctx, oracle):
+    import torch
+    fmt = alac_amd.make_format(4096, 16, 2)
+    enc = oracle.encoder(4096, 16, 2)
+    pk = enc.encode_packet(alac_amd.synth_pcm(3, 1, fmt), 4096)
+    offs = torch.tensor([0, len(pk)], dtype=torch.int64, device="cuda")
+    for field, value in ((8, 0), (8, 17), (6, 0)):  # kb = 0, kb = 17, pb = 0
+        ck = enc.cookie().copy()
+        ck[field] = value
+        with pytest.raises(RuntimeError):
+            gpu_ctx.decode(ck, torch.from_numpy(pk).cuda(), offs, 1)
