@@ -71,6 +71,7 @@ SIGNATURES = {
     "alac_hip_decode_host": (_i32, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _vp]),
     "alac_synth_frame": (None, [_u64, _u32, _u32, _u32, _vp]),
     "alac_synth_pcm": (None, [_u64, _u32, _u32, _u32, _u32, _vp]),
+    "alac_hip_synth_pcm": (_i32, [_vp, _u64, _u32, C.POINTER(Format), _vp]),
 }
 
 _lib = None
@@ -159,6 +160,16 @@ class Context:
     def synchronize(self):
         self._check(self.lib.alac_hip_synchronize(self.h))
 
+    def synth_pcm(self, first_frame, num_frames, fmt, out=None):
+        """The synthetic PCM of frames [first_frame, first_frame + num_frames) generated ON THE DEVICE (same bytes as
+        synth_pcm(): one generator source) -> uint8 cuda tensor."""
+        t = self.torch
+        if out is None:
+            out = t.empty(num_frames * fmt.packet_bytes, dtype=t.uint8, device=self.device)
+        assert out.numel() >= num_frames * fmt.packet_bytes
+        self._check(self.lib.alac_hip_synth_pcm(self.h, first_frame, num_frames, C.byref(fmt), out.data_ptr()))
+        return out
+
     # ---- encode ----------------------------------------------------------------------------
     def encode_buffers(self, fmt, num_packets):
         """Preallocate outputs so a timed loop does no allocation."""
@@ -194,6 +205,24 @@ class Context:
         self.synchronize()
         total = int(b["offsets"][-1].item())
         return b["out"][:total].cpu().numpy(), b["sizes"].cpu().numpy().astype(np.uint32)
+
+    def encode_host(self, fmt, pcm, total_samples, segment_packets=0, state=None):
+        """alac_hip_encode_host: host PCM (uint8 ndarray, total_samples sample-frames) -> (stream ndarray, sizes ndarray,
+        final state ndarray).  segment_packets = 0: ONE chained segment (a whole file); k: state reset every k packets.
+        Synchronous (does its own H2D / D2H)."""
+        pcm = np.ascontiguousarray(pcm, np.uint8)
+        npk = (total_samples + fmt.frame_size - 1) // fmt.frame_size
+        nseg = (npk + segment_packets - 1) // segment_packets if segment_packets else 1
+        cap = int(self.lib.alac_hip_encode_max_output_bytes(C.byref(fmt), npk))
+        out = np.zeros(cap, np.uint8)
+        sizes = np.zeros(max(npk, 1), np.uint32)
+        n16 = int(self.lib.alac_hip_state_int16(C.byref(fmt)))
+        st = np.zeros(nseg * n16, np.int16) if state is None else np.ascontiguousarray(state, np.int16).copy()
+        total = _u64(0)
+        self._check(self.lib.alac_hip_encode_host(self.h, C.byref(fmt), pcm.ctypes.data, total_samples, segment_packets,
+                                                  st.ctypes.data, 0 if state is None else 1, out.ctypes.data, cap,
+                                                  sizes.ctypes.data, C.byref(total)))
+        return out[:total.value].copy(), sizes[:npk].copy(), st
 
     def profile_begin(self, max_calls):
         self._check(self.lib.alac_hip_profile_begin(self.h, max_calls))

@@ -209,6 +209,11 @@ void alac_synth_frame(uint64_t frame_index, uint32_t num_samples, uint32_t bit_d
                       uint32_t channels, uint8_t *h_out);
 void alac_synth_pcm(uint64_t first_frame, uint32_t num_frames, uint32_t frame_size,
                     uint32_t bit_depth, uint32_t channels, uint8_t *h_out);
+/* The same generator on the device (same source, same bytes): frames [first_frame, first_frame + num_frames) of
+ * fmt->frame_size sample-frames each, written back to back at d_out on the context's stream (1 or 2 channels).
+ * BASELINE.json configs[3]: every rank generates its own shard in HBM. */
+int32_t alac_hip_synth_pcm(alac_hip_ctx *ctx, uint64_t first_frame, uint32_t num_frames,
+                           const alac_hip_format *fmt, uint8_t *d_out);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,9 @@ Outputs (data only — inputs and expected outputs, no reference source):
                       pc_block/dyn_comp, chained and independent
   known_answers.json  sizes / FNV-1a-64 of whole-file encodes of the three reference WAVs and of the
                       synthetic workload (pins the generator too)
+  wav50_pcm.xz,       the sample data of the reference's audio/50.wav (stereo, 237 packets) and audio/05.wav (mono, 302
+  wav05_pcm.xz        packets), xz-compressed: the INPUTS of the whole-file known answers, so that the GPU box (which has
+                      no /root/reference) can encode the full-length chains (tests/test_gpu_wholefile.py)
 """
 import json
 import os
@@ -125,6 +128,15 @@ def make_packets(o, r):
     print("packets.npz written")
 
 
+def make_wav_pcm_fixtures():
+    import lzma
+    for name, out in (("50.wav", "wav50_pcm.xz"), ("05.wav", "wav05_pcm.xz")):
+        ch, rate, bits, data = read_wav(os.path.join(REF_AUDIO, name))
+        with open(os.path.join(HERE, out), "wb") as f:
+            f.write(lzma.compress(data.tobytes(), preset=9 | lzma.PRESET_EXTREME))
+        print(out, "written:", os.path.getsize(os.path.join(HERE, out)), "bytes for", data.size, "bytes of PCM")
+
+
 def make_known_answers(o, r):
     import alac_amd
     H = r.hooks()
@@ -162,3 +174,4 @@ if __name__ == "__main__":
     make_stage_vectors(o, r)
     make_packets(o, r)
     make_known_answers(o, r)
+    make_wav_pcm_fixtures()

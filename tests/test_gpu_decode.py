@@ -120,11 +120,10 @@ def test_fill_and_data_elements_are_skipped_and_may_exceed_the_regular_stream_bo
         enc.reset()
         e = _element_bits(enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], 4096))
         if p % 3 == 0:
-            b = _fil(270) + e
+            b = _fil(269) + e
         elif p % 3 == 1:
-            head = _dse(300, 1)
-            head += [0] * (-len(head) % 8) + [1, 1, 0, 0] * (2 * 300)
-            b = _fil(3) + head + e
+            head = _fil(3) + _dse(300, 1)
+            b = head + [0] * (-len(head) % 8) + [1, 1, 0, 0] * (2 * 300) + e
         else:
             b = _dse(7, 0) + [0, 1] * (4 * 7) + e
         pks.append(np.packbits(np.array(b + [1, 1, 1], np.uint8)))

@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the N > 1 path of bench.py (shard -> encode -> re-assemble) gives the
-same stream as one process encoding everything.  Shards are encoded with the CPU oracle here; on the
-GPU node the same reassemble_shards() runs over RCCL."""
+same stream as one process encoding everything.  Shards are encoded with the CPU oracle here (ragged shard lengths,
+so the grouped send/receive places every shard at a different, unaligned offset); on the GPU node the same
+Reassembler runs over RCCL."""
 import os
 import sys
 
@@ -28,8 +29,9 @@ def _worker(rank, world, port, per_rank, q):
     shard = torch.zeros(cap, dtype=torch.uint8)
     shard[:len(s)] = torch.from_numpy(s)
     res = None
+    t_sizes = torch.from_numpy(sizes.astype(np.int32))
     for _ in range(2):  # second call reuses the cached buffers
-        res = reassemble_shards(shard, torch.tensor([len(s)], dtype=torch.int64), None, res)
+        res = reassemble_shards(shard, torch.tensor([len(s)], dtype=torch.int64), None, res, sizes=t_sizes)
     # the pipelined two-phase form (what bench.py uses at N > 1) must give the same stream
     ra = Reassembler()
     h1 = ra.begin(shard, torch.tensor([len(s)], dtype=torch.int64))
@@ -38,16 +40,20 @@ def _worker(rank, world, port, per_rank, q):
     first = r1["stream"][:r1["total"]].clone()
     r2 = ra.finish(h2)
     assert torch.equal(first, res["stream"][:res["total"]]) and torch.equal(r2["stream"][:r2["total"]], first)
-    q.put((rank, res["stream"][:res["total"]].numpy().copy(), res["offsets"].numpy().copy()))
+    q.put((rank, res["stream"][:res["total"]].numpy().copy(), res["offsets"].numpy().copy(), res["sizes"].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_reassembly_equals_single_stream():
+import pytest
+
+
+@pytest.mark.parametrize("WORLD", [2, 3])
+def test_rank_reassembly_equals_single_stream(WORLD):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import alac_amd
     from oracle_lib import Oracle
-    world, per_rank = 2, 12
+    world, per_rank = WORLD, 12
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
@@ -61,6 +67,7 @@ def test_two_rank_reassembly_equals_single_stream():
     fmt = alac_amd.make_format(4096, 16, 2)
     pcm = alac_amd.synth_pcm(0, world * per_rank, fmt)
     want, sizes = Oracle().encoder(4096, 16, 2).encode_stream(pcm, world * per_rank * 4096, 1)
-    for rank, stream, offsets in got:
+    for rank, stream, offsets, all_sizes in got:
         assert np.array_equal(stream, want), f"rank {rank}"
         assert offsets[-1] == len(want) and offsets[1] == int(sizes[:per_rank].sum())
+        assert np.array_equal(all_sizes.astype(np.uint32), sizes)  # the 'pakt' table of the whole stream
