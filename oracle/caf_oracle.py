@@ -8,9 +8,13 @@ computes the same layout in one pass without seeking; the tests compare the two 
 The codec itself is injected: `encode_packet(pcm_bytes, num_frames) -> bytes` (chained, e.g. the C oracle's
 encoder) and `decode_packet(packet_bytes) -> (pcm_bytes, num_frames)`.
 
-Parity pin: the reference's alacconvert cannot be built here (its main.cu / ALACEncoder.cu need CUDA), so this
-restatement is pinned by the reference's own known answers recorded in SURVEY.md §8c/§8f (header bytes, table
-entry widths, the phantom packet, 50.wav -> 237 packets / 1 164 578 payload bytes) and by round trips.
+Parity pin: the reference's alacconvert cannot be built here (its main.cu / ALACEncoder.cu need CUDA), but its container
+code can: oracle/Makefile compiles convert-utility/CAFFileALAC.cpp where it lies into oracle/_ref/libcafref.so, and
+tests/test_container_refpin.py checks every chunk writer, the BER coder, base_packet_table and whole product-written
+files against it (and against the committed fixture tests/golden/caf_headers.json where /root/reference is absent).
+The seek-and-patch SEQUENCE of main.cu (which chunk when, the free-chunk fix-up) is restated and pinned by the known
+answers recorded in SURVEY.md §8c/§8f (table entry widths, the phantom packet, 50.wav -> 237 packets / 1 164 578 payload
+bytes) and by round trips.
 """
 import struct
 

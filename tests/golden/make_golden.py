@@ -12,6 +12,7 @@ Outputs (data only — inputs and expected outputs, no reference source):
                       pc_block/dyn_comp, chained and independent
   known_answers.json  sizes / FNV-1a-64 of whole-file encodes of the three reference WAVs and of the
                       synthetic workload (pins the generator too)
+  caf_headers.json    chunk bytes, BER codes and base packet tables from the reference's own CAFFileALAC.cpp
   wav50_pcm.xz,       the sample data of the reference's audio/50.wav (stereo, 237 packets) and audio/05.wav (mono, 302
   wav05_pcm.xz        packets), xz-compressed: the INPUTS of the whole-file known answers, so that the GPU box (which has
                       no /root/reference) can encode the full-length chains (tests/test_gpu_wholefile.py)
@@ -137,6 +138,15 @@ def make_wav_pcm_fixtures():
         print(out, "written:", os.path.getsize(os.path.join(HERE, out)), "bytes for", data.size, "bytes of PCM")
 
 
+def make_caf_headers():
+    """CAF chunk bytes / BER codes / base packet tables from the reference's own CAFFileALAC.cpp (oracle/_ref/libcafref.so)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import test_container_refpin as t
+    with open(os.path.join(HERE, "caf_headers.json"), "w") as f:
+        json.dump(t.collect(t.CafRef()), f, indent=0, sort_keys=True)
+    print("caf_headers.json written")
+
+
 def make_known_answers(o, r):
     import alac_amd
     H = r.hooks()
@@ -175,3 +185,4 @@ if __name__ == "__main__":
     make_packets(o, r)
     make_known_answers(o, r)
     make_wav_pcm_fixtures()
+    make_caf_headers()

@@ -172,6 +172,12 @@ def test_stream_beyond_the_workspace_fails_cleanly(gpu_ctx, oracle):
     assert rc == 0
     gpu_ctx.synchronize()
     st = st.cpu().tolist()
+    import os
+    if os.environ.get("ALAC_HIP_DECODER") == "lane":
+        # the first-generation decoder reads the packets where they lie (no staged copy): everything decodes
+        assert st == [0] * n
+        assert np.array_equal(out.cpu().numpy(), pcm)
+        return
     assert st[0] == 0 and st[-1] == -50 and all(s in (0, -50) for s in st)
     assert st == sorted(st, reverse=True)  # a prefix decodes, the tail fails
     k = st.index(-50)
