@@ -87,8 +87,8 @@ struct EncLayout {
     uint32_t wcap;
     uint64_t predStride;
     // tap-parallel pipeline: residual planes [sample][stream], decision scratch, working state
-    uint64_t resA, resB, resC, bits1, cost2, state, flags;
-    uint32_t chainsPad;
+    uint64_t resA, resB, resC, bits1, cost2, state, flags, cls, colChain;
+    uint32_t chainsPad, colsPad;
 };
 
 EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t numSegments)
@@ -114,8 +114,10 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     off = align_up(off + (f->num_channels == 2 ? n8 * 5 * lanes * 4 : 0), 256);
     L.resB = off;
     off = align_up(off + n8 * 2 * lanes * 4, 256);
+    // final residuals: columns handed out per packet class (k_class_assign), two regions padded to 64 -> up to 128 spare
+    L.colsPad = (uint32_t)lanes + 128;
     L.resC = off;
-    off = align_up(off + ((uint64_t)f->frame_size + 16) * lanes * 4, 256);
+    off = align_up(off + ((uint64_t)f->frame_size + 16) * L.colsPad * 4, 256);
     L.bits1 = off;
     off = align_up(off + 5 * lanes * 4, 256);
     L.cost2 = off;
@@ -123,7 +125,11 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.state = off;
     off = align_up(off + (uint64_t)numSegments * 128, 256);
     L.flags = off;
-    off = align_up(off + (lanes / 32 + 4) * 4, 256);
+    off = align_up(off + (lanes / 8 + 16) * 4, 256);  // one word per predictor wave: up to colsPad / 16 + colsPad / 32 of them
+    L.cls = off;  // ClassInfo + per-1024-packet class counts of the compaction
+    off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2) * 8, 256);
+    L.colChain = off;
+    off = align_up(off + (uint64_t)L.colsPad * 4, 256);
     L.total = off;
     return L;
 }
@@ -594,6 +600,9 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
         vb.cost2 = (uint32_t *)(ws + L.cost2);
         vb.flags = (uint32_t *)(ws + L.flags);
         vb.chainsPad = L.chainsPad;
+        vb.cls = ws + L.cls;
+        vb.colChain = (uint32_t *)(ws + L.colChain);
+        vb.colsPad = L.colsPad;
         vb.ho = handoff_ctl(ctx);
         e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, ctx->vs, num_packets, maxSeg, ctx->stream, ev);
     }

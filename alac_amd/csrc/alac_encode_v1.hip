@@ -41,8 +41,10 @@ constexpr int kTile = 64;         // predictor steps per LDS tile
 constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; 12 keeps
                                   // the 16-byte PCM loads of the staging aligned)
 constexpr int kRowLen = kHist + kTile + 4;  // 80 staged samples per row
-constexpr int kXsStride = 89;     // dwords per input row: >= kRowLen + 8 (operand prefetch over-read), odd
-constexpr int kResStride = 65;    // dwords per residual row, odd
+constexpr int kXsStride = 89;     // dwords per input row: >= kRowLen + 9 (operand prefetch over-read / warm-up parking), odd
+// Residuals are written IN PLACE: res[j] goes to cell j - j0 of the chain's input row, which held x[j - kHist]; the oldest
+// input any later step (or operand prefetch) still reads is x[j - 1 - 8], four cells further on.  One LDS array per
+// wave: 11.7 KB for 32 chains, 23 KB for 64 — twice the waves per CU a separate residual tile allowed.
 constexpr int kZeroCells = 24;    // zeros fed to lanes that hold no active tap
 
 struct SegView {
@@ -131,6 +133,18 @@ struct RowWait {
     }
 };
 
+constexpr uint32_t kNoChain = 0xffffffffu;
+
+// What k_class_count / k_class_assign leave for the final pass: the packets that still need it (not escaped, present at this packet
+// position), grouped by the widest predictor they chose.  Columns [0, n8) carry the chains of packets with an 8-tap
+// channel, [base4, base4 + n4) the chains of all-4-tap packets; both regions are padded to whole coder waves (64).
+// A packet's channels sit in adjacent columns, so the staging still mixes U and V from one PCM load.
+struct ClassInfo {
+    uint32_t n8, n4;     // chains (columns in use) per class
+    uint32_t base4;      // first column of the 4-tap region = n8 rounded up to 64
+    uint32_t nCols;      // base4 + n4 rounded up to 64
+};
+
 struct V1Args {
     SegView S;
     int16_t *state;        // [segment][64] working coefficient rows
@@ -149,6 +163,12 @@ struct V1Args {
     uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
     uint32_t idleFast;     // 1: lanes without work do not force the checked paths (latency regime, see launcher)
     HandoffCtl ho;         // error word / spin bound / test switch of the in-launch hand-offs
+    uint32_t wide81;       // 1: 8-tap rows of the searches run with all taps in one lane (throughput regime)
+    uint32_t thru;         // 1: throughput regime (see launch_v1_typed)
+    // final pass by packet class (k_class_count, k_class_assign): columns of the residual plane are handed out per class
+    ClassInfo *cls;
+    uint32_t *colChain;    // [colsPad] chain (segment * CH + channel) of every column, kNoChain for pad columns
+    uint32_t colsPad;      // row stride of resC in the class layout
 };
 
 // ================================================================================================
@@ -159,8 +179,8 @@ struct V1Args {
 template <int LPC>
 struct LmsShared {
     static constexpr int SLOTS = 64 / LPC;
-    int32_t xs[SLOTS * kXsStride];      // chain inputs (mixed / widened samples), one row per chain
-    int32_t res[(SLOTS + 1) * kResStride];  // residual tile per chain (+ one dump row for inert lanes)
+    int32_t xs[(SLOTS + 1) * kXsStride];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
+                                          // the residuals as the steps pass (+ one dump row for inert lanes)
     int32_t zero[kZeroCells];
     uint32_t pktIdx[SLOTS], pktN[SLOTS];  // per input row: packet and its valid samples
     int32_t rowMix[SLOTS];                // mixRes of the row's packet (this pass)
@@ -406,18 +426,17 @@ __device__ __forceinline__ void load_ops(StepOps &o, const int32_t *pn, const in
     }
 }
 
-template <int LPC, bool MASKED>
-__device__ __forceinline__ void run_block(int32_t (&a)[4], int32_t (&w)[4], const StepOps &o, const LmsLane &L, int jb,
+template <int T, int LPC, bool MASKED>
+__device__ __forceinline__ void run_block(int32_t (&a)[T], int32_t (&w)[T], const StepOps &o, const LmsLaneT<T> &L, int jb,
                                           int32_t *resAt, uint32_t chanbits)
 {
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         const int j = jb + s;
         const int32_t liveMask = MASKED ? (((j >= L.jlo) & (j < L.jhi)) ? -1 : 0) : -1;
-        resAt[s] = lms4_step<LPC, MASKED>(a, w, o.tp[s], o.cu[s], liveMask, L, chanbits);
-        w[3] = w[2];
-        w[2] = w[1];
-        w[1] = w[0];
+        resAt[s] = lms_step<T, LPC, MASKED>(a, w, o.tp[s], o.cu[s], liveMask, L, chanbits);
+#pragma unroll
+        for (int i = T - 1; i > 0; i--) w[i] = w[i - 1];
         w[0] = o.nx[s];
     }
 }
@@ -431,18 +450,18 @@ struct LaneView {
 };
 
 // one tile [j0, jEnd) of steps; the history windows are (re)loaded from LDS at the tile start
-template <int LPC>
-__device__ __forceinline__ void run_tile(int32_t (&a)[4], const LaneView &V, const LmsLane &L, int j0, int jEnd,
+template <int T, int LPC>
+__device__ __forceinline__ void run_tile(int32_t (&a)[T], const LaneView &V, const LmsLaneT<T> &L, int j0, int jEnd,
                                          uint32_t chanbits)
 {
     const int adv = V.feeds ? 1 : 0;
-    // x[j] lives at row[kHist + j - j0].  nx of step j = x[j - 4h] enters the window for step j + 1
-    const int32_t *pn = V.feeds ? V.row + kHist - 4 * L.h : V.zero;
+    // x[j] lives at row[kHist + j - j0].  nx of step j = x[j - T h] enters the window for step j + 1
+    const int32_t *pn = V.feeds ? V.row + kHist - T * L.h : V.zero;
     const int32_t *pt = V.feeds ? V.row + kHist - 1 - L.na : V.zero;
     const int32_t *pc = V.row + kHist;
-    int32_t w[4];
+    int32_t w[T];
 #pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = V.feeds ? V.row[kHist - 1 - 4 * L.h - i] : 0;
+    for (int i = 0; i < T; i++) w[i] = V.feeds ? V.row[kHist - 1 - T * L.h - i] : 0;
     StepOps opA, opB;  // ping-pong: no register copies between blocks
     load_ops(opA, pn, pt, pc);
     auto block = [&](const StepOps &cur, StepOps &nxt, int jb) {
@@ -450,9 +469,9 @@ __device__ __forceinline__ void run_tile(int32_t (&a)[4], const LaneView &V, con
         load_ops(nxt, pn + adv * (o + 8), pt + adv * (o + 8), pc + (o + 8));
         const bool allLive = __all((jb >= L.jlo) & (jb + 8 <= L.jhi));  // wave-uniform
         if (allLive)
-            run_block<LPC, false>(a, w, cur, L, jb, V.res + o, chanbits);
+            run_block<T, LPC, false>(a, w, cur, L, jb, V.res + o, chanbits);
         else
-            run_block<LPC, true>(a, w, cur, L, jb, V.res + o, chanbits);
+            run_block<T, LPC, true>(a, w, cur, L, jb, V.res + o, chanbits);
     };
     for (int jb = j0; jb < jEnd; jb += 16) {
         block(opA, opB, jb);
@@ -472,8 +491,8 @@ struct ChainJob {
 // A pass = one pc_block call over every chain of the wave: `num` samples adapt the row, residual positions
 // j < P go to dst[j * streamStride + stream] when store is set.
 // ZZ: residuals leave as their zig-zag image 2|del| - (del < 0) (what the final entropy coder starts from)
-template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false>
-__device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[4],
+template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false, int T = 4>
+__device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[T],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
                                          uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0,
                                          StageRegs<CH, LPC> *head = nullptr, int headMode = 0)
@@ -485,7 +504,7 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
     const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
     const int slot = lane / LPC;
-    LmsLane L = make_lane<LPC>(lane, J.na, J.active ? (int)num : 0);
+    LmsLaneT<T> L = make_lane<T, LPC>(lane, J.na, J.active ? (int)num : 0);
     // Lanes without work (pad lanes, escape packets in the final pass) must not drag the wave onto the checked
     // paths: they count as "live", as owning every row and as fully inside their packet.  What they compute and
     // store goes to rows / slots nobody reads.
@@ -495,9 +514,9 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
         L.jhi = 0x7fffffff;
     }
     LaneView V;
-    V.feeds = J.active && (4 * L.h < J.na);
+    V.feeds = J.active && (T * L.h < J.na);
     V.row = sh.xs + slot * kXsStride;
-    V.res = V.feeds ? sh.res + slot * kResStride : sh.res + SLOTS * kResStride;
+    V.res = V.feeds ? sh.xs + slot * kXsStride : sh.xs + SLOTS * kXsStride;
     V.zero = sh.zero;
     // the lane that flushes slot fs = lane % SLOTS needs that slot's P / stream / activity
     const int fs = lane % SLOTS;
@@ -536,16 +555,23 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
         if (fastNext) stage_load_fast<DEPTH, CH, LPC>(R, SP, j0 + kTile);  // in flight under the tile
         else if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
         lds_order();
+        // warm-up positions of pc_block (dp_enc.c:90, :108-112): pc[0] = in[0], pc[j] = sext(in[j] - in[j-1]).  They are
+        // formed from x[0 .. na] BEFORE the steps overwrite those cells with residuals and parked in the row's prefetch
+        // over-read cells (kRowLen .. kRowLen + 8, never data), then moved to cells 0 .. na once the tile has run.
+        if (store && j0 == 0) {
+            for (int pos = lane / SLOTS; pos <= fNa; pos += LPC) {
+                const int32_t *xr = sh.xs + fs * kXsStride + kHist;
+                sh.xs[fs * kXsStride + kRowLen + pos] = pos == 0 ? xr[0] : sext(xr[pos] - xr[pos - 1], 32 - chanBits);
+            }
+            lds_order();
+        }
         const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
-        run_tile<LPC>(a, V, L, j0, jEnd, chanBits);
+        run_tile<T, LPC>(a, V, L, j0, jEnd, chanBits);
         lds_order();
         if (store) {
-            // warm-up positions of pc_block (dp_enc.c:90, :108-112): pc[0] = in[0], pc[j] = sext(in[j] - in[j-1])
             if (j0 == 0) {
-                for (int pos = lane / SLOTS; pos <= fNa; pos += LPC) {
-                    const int32_t *xr = sh.xs + fs * kXsStride + kHist;
-                    sh.res[fs * kResStride + pos] = pos == 0 ? xr[0] : sext(xr[pos] - xr[pos - 1], 32 - chanBits);
-                }
+                for (int pos = lane / SLOTS; pos <= fNa; pos += LPC)
+                    sh.xs[fs * kXsStride + pos] = sh.xs[fs * kXsStride + kRowLen + pos];
                 lds_order();
             }
             // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams.  WT (fused launches):
@@ -560,13 +586,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 int32_t *tileBase = dst + (uint64_t)j0 * streamStride;
 #pragma unroll
                 for (int it = 0; it < kTile / LPC; it++)
-                    put(tileBase + (uint64_t)(it * LPC) * streamStride + voff, sh.res[fs * kResStride + it * LPC + (int)half]);
+                    put(tileBase + (uint64_t)(it * LPC) * streamStride + voff, sh.xs[fs * kXsStride + it * LPC + (int)half]);
             } else {
 #pragma unroll 4
                 for (int it = 0; it < kTile / LPC; it++) {
                     const int jj = it * LPC + lane / SLOTS;
                     const uint32_t j = (uint32_t)(j0 + jj);
-                    const int32_t v = sh.res[fs * kResStride + jj];
+                    const int32_t v = sh.xs[fs * kXsStride + jj];
                     if (j < fP) put(dst + (uint64_t)j * streamStride + fStream, v);
                 }
             }
@@ -594,46 +620,58 @@ __device__ __forceinline__ void lms_setup(LmsShared<LPC> &sh, const ChainJob &J,
     lds_order();
 }
 
-template <int LPC>
-__device__ __forceinline__ void load_row(const ChainJob &J, int32_t (&a)[4], int lane)
+template <int LPC, int T = 4>
+__device__ __forceinline__ void load_row(const ChainJob &J, int32_t (&a)[T], int lane)
 {
-    const int h = LPC == 2 ? (lane & 1) : 0;
+    const int h = lane & (LPC - 1);
 #pragma unroll
-    for (int i = 0; i < 4; i++) a[i] = (J.active && 4 * h + i < J.na) ? (int32_t)J.row[4 * h + i] : 0;
+    for (int i = 0; i < T; i++) a[i] = (J.active && T * h + i < J.na) ? (int32_t)J.row[T * h + i] : 0;
 }
 
-template <int LPC>
-__device__ __forceinline__ void store_row(const ChainJob &J, const int32_t (&a)[4], int lane)
+template <int LPC, int T = 4>
+__device__ __forceinline__ void store_row(const ChainJob &J, const int32_t (&a)[T], int lane)
 {
-    const int h = LPC == 2 ? (lane & 1) : 0;
+    const int h = lane & (LPC - 1);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (J.active && 4 * h + i < J.na) J.row[4 * h + i] = (int16_t)a[i];
+    for (int i = 0; i < T; i++)
+        if (J.active && T * h + i < J.na) J.row[T * h + i] = (int16_t)a[i];
 }
 
 // ---- k_lms_search1: the five mixRes passes over N/8 samples walking row 7 (codec/ALACEncoder.cu:353-379)
-template <int DEPTH>
-__global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
+// T taps per lane x L lanes per chain = 8 (alac_lms.hpp "lane mappings"): <4, 2> or <8, 1>
+template <int DEPTH, int T, int L>
+__device__ __forceinline__ void search1_predictor(LmsShared<L> &sh, const V1Args &A, uint32_t block, int lane, uint32_t *flag)
 {
-    __shared__ LmsShared<2> sh;
-    const int lane = threadIdx.x;
+    constexpr int SLOTS = 64 / L;
     ChainJob J;
-    const uint32_t chain = A.S.segBegin * 2 + blockIdx.x * 32u + lane / 2;
+    const uint32_t chain = A.S.segBegin * 2 + block * SLOTS + lane / L;
     J.seg = chain >> 1;
     J.ch = chain & 1;
     J.active = seg_packet(A.S, J.seg, J.p, J.N);
     J.na = 8;
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
-    int32_t a[4];
-    load_row<2>(J, a, lane);
+    int32_t a[T];
+    load_row<L>(J, a, lane);
     const uint32_t n8 = J.N / 8;
-    StageRegs<2, 2> head;
+    StageRegs<2, L> head;
     for (int r = 0; r <= kMaxRes; r++) {
-        lms_setup<2>(sh, J, r, lane);
-        lms_pass<DEPTH, 2, 2>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
-                              nullptr, 0, &head, r == 0 ? 1 : 2);
+        lms_setup<L>(sh, J, r, lane);
+        if (flag)
+            lms_pass<DEPTH, 2, L, true>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain,
+                                        lane, flag, (uint32_t)r << 16, &head, r == 0 ? 1 : 2);
+        else
+            lms_pass<DEPTH, 2, L>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
+                                  nullptr, 0, &head, r == 0 ? 1 : 2);
     }
-    store_row<2>(J, a, lane);
+    store_row<L>(J, a, lane);
+    if (flag) publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);
+}
+
+template <int DEPTH, int T, int L>
+__global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
+{
+    __shared__ LmsShared<L> sh;
+    search1_predictor<DEPTH, T, L>(sh, A, blockIdx.x, threadIdx.x, nullptr);
 }
 
 // ---- k_lms_search2: converge passes for numUV = 4 (row 3, one lane per chain) and 8 (row 7, two lanes per
@@ -736,32 +774,14 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
 
 // ---- k_search1_fused: k_lms_search1 and k_gol_count1 in one launch.  Workgroups [0, nLms) walk the five
 // mixRes passes and publish (pass << 16) + rows; the count waves of pass r follow them through plane r.
-template <int DEPTH>
+template <int DEPTH, int T, int L>
 __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, uint32_t cblocks, uint32_t chanBits)
 {
-    __shared__ LmsShared<2> sh;
+    __shared__ LmsShared<L> sh;
     __shared__ uint32_t recip[17];
     const int lane = threadIdx.x;
     if (blockIdx.x < nLms) {
-        ChainJob J;
-        const uint32_t chain = A.S.segBegin * 2 + blockIdx.x * 32u + lane / 2;
-        J.seg = chain >> 1;
-        J.ch = chain & 1;
-        J.active = seg_packet(A.S, J.seg, J.p, J.N);
-        J.na = 8;
-        J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
-        int32_t a[4];
-        load_row<2>(J, a, lane);
-        const uint32_t n8 = J.N / 8;
-        uint32_t *flag = A.flags + blockIdx.x;
-        StageRegs<2, 2> head;
-        for (int r = 0; r <= kMaxRes; r++) {
-            lms_setup<2>(sh, J, r, lane);
-            lms_pass<DEPTH, 2, 2, true>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain,
-                                        lane, flag, (uint32_t)r << 16, &head, r == 0 ? 1 : 2);
-        }
-        store_row<2>(J, a, lane);
-        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);
+        search1_predictor<DEPTH, T, L>(sh, A, blockIdx.x, lane, A.flags + blockIdx.x);
     } else {
         gol_table_init(recip, lane);
         __syncthreads();
@@ -775,9 +795,10 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         const uint64_t stride = 5ull * A.chainsPad;
         GolF g;
         golf_reset(g);
+        // the 64 chains of this wave come from 64 / (64 / L) = L producer waves
         RowWait wait;
-        wait.f0 = A.flags + 2 * w;
-        wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
+        wait.f0 = A.flags + L * w;
+        wait.f1 = (L == 2 && 2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
         wait.base = r << 16;
         wait.ho = A.ho;
@@ -958,7 +979,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         golf_reset(g);
         g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
         g.wleft = A.wcap - 1;
-        RowWait wait;
+            RowWait wait;
         wait.f0 = A.flags + 2 * w;
         wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
         wait.avail = 0;
@@ -968,6 +989,202 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         golf_flush<true>(g);
         if (active) rec->c[c].bits = g.bits;
     }
+}
+
+// ================================================================================================
+// Final pass by packet class.  After k_decide2 a packet is (a) escaped — nothing left to predict or code, (b) all
+// channels on 4 taps, (c) at least one channel on 8 taps.  The v1 final launch ran every chain of the batch on the
+// 2-lanes-x-4-taps mapping; here the chains are compacted per class so that each class gets the lane mapping that fits
+// it (alac_lms.hpp "lane mappings") and escaped packets cost nothing:
+//   throughput regime   8-tap class <8, 1>, 4-tap class <4, 1>: 64 chains per wave, fewest instructions per chain step
+//   latency regime      8-tap class <4, 2> / <2, 4>, 4-tap class <4, 1> / <2, 2>: fewer instructions per wave step
+// ================================================================================================
+
+// class of packet i of this position: 0 = nothing to do (no packet here, or escaped), else 4 or 8
+template <int CH>
+__device__ __forceinline__ uint32_t packet_class(const V1Args &A, uint32_t i, uint32_t nseg)
+{
+    if (i >= nseg) return 0;
+    uint32_t p, N;
+    if (!seg_packet(A.S, A.S.segBegin + i, p, N)) return 0;
+    const PacketRec *rec = A.recs + p;
+    if (rec->escape) return 0;
+    uint32_t widest = rec->c[0].num;
+    if (CH == 2 && rec->c[1].num > widest) widest = rec->c[1].num;
+    return widest == 8 ? 8u : 4u;
+}
+
+// Deterministic compaction in packet order, two launches of 1024-packet workgroups:
+//   k_class_count   per workgroup: packets of each class -> blockCnt[b] = {count8, count4}
+//   k_class_assign  per workgroup: its base = sum of the counts before it (every workgroup adds them up itself: a few
+//                   hundred words), columns by ballot rank; the last workgroup writes ClassInfo and the pad columns
+template <int CH>
+__global__ __launch_bounds__(1024) void k_class_count(V1Args A, uint32_t *blockCnt)
+{
+    __shared__ uint32_t wcnt[2][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+    const uint32_t c = packet_class<CH>(A, blockIdx.x * 1024u + tid, nseg);
+    const uint64_t m8 = __ballot(c == 8), m4 = __ballot(c == 4);
+    if (lane == 0) {
+        wcnt[0][wv] = (uint32_t)__popcll(m8);
+        wcnt[1][wv] = (uint32_t)__popcll(m4);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < 16; q++) t += wcnt[tid][q];
+        blockCnt[blockIdx.x * 2 + tid] = t;
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void k_class_assign(V1Args A, const uint32_t *blockCnt)
+{
+    __shared__ uint32_t wcnt[2][16];
+    __shared__ uint32_t part[4][16];  // before-me / total, per class, per wave
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+    const uint32_t nblk = gridDim.x, b = blockIdx.x;
+    // sums of the per-workgroup counts: before this workgroup, and in all
+    uint32_t before8 = 0, before4 = 0, all8 = 0, all4 = 0;
+    for (uint32_t q = tid; q < nblk; q += 1024) {
+        const uint32_t a8 = blockCnt[2 * q], a4 = blockCnt[2 * q + 1];
+        all8 += a8;
+        all4 += a4;
+        if (q < b) {
+            before8 += a8;
+            before4 += a4;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        before8 += (uint32_t)__shfl_xor((int)before8, d);
+        before4 += (uint32_t)__shfl_xor((int)before4, d);
+        all8 += (uint32_t)__shfl_xor((int)all8, d);
+        all4 += (uint32_t)__shfl_xor((int)all4, d);
+    }
+    if (lane == 0) {
+        part[0][wv] = before8;
+        part[1][wv] = before4;
+        part[2][wv] = all8;
+        part[3][wv] = all4;
+    }
+    const uint32_t c = packet_class<CH>(A, b * 1024u + tid, nseg);
+    const uint64_t m8 = __ballot(c == 8), m4 = __ballot(c == 4);
+    if (lane == 0) {
+        wcnt[0][wv] = (uint32_t)__popcll(m8);
+        wcnt[1][wv] = (uint32_t)__popcll(m4);
+    }
+    __syncthreads();
+    uint32_t s[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < 16; q++) {
+        s[0] += part[0][q];
+        s[1] += part[1][q];
+        s[2] += part[2][q];
+        s[3] += part[3][q];
+    }
+    const uint32_t n8 = s[2] * CH, n4 = s[3] * CH, base4 = (n8 + 63) & ~63u, nCols = (base4 + n4 + 63) & ~63u;
+    if (c) {
+        const uint32_t k = c == 8 ? 0 : 1;
+        uint32_t r = s[k] + (uint32_t)__popcll((k ? m4 : m8) & ((1ull << lane) - 1));
+        for (uint32_t q = 0; q < wv; q++) r += wcnt[k][q];
+        const uint32_t col = (k ? base4 : 0u) + r * CH;
+        const uint32_t chain = (A.S.segBegin + b * 1024u + tid) * CH;
+        A.colChain[col] = chain;
+        if (CH == 2) A.colChain[col + 1] = chain + 1;
+    }
+    if (b + 1 == nblk) {
+        for (uint32_t q = n8 + tid; q < base4; q += 1024) A.colChain[q] = kNoChain;
+        for (uint32_t q = base4 + n4 + tid; q < nCols; q += 1024) A.colChain[q] = kNoChain;
+        if (tid == 0) {
+            A.cls->n8 = n8;
+            A.cls->n4 = n4;
+            A.cls->base4 = base4;
+            A.cls->nCols = nCols;
+        }
+    }
+}
+
+// the chain of a column -> what lms_pass needs
+template <int CH>
+__device__ __forceinline__ void class_job(const V1Args &A, uint32_t col, uint32_t limit, ChainJob &J, int &best)
+{
+    const uint32_t chain = col < limit ? A.colChain[col] : kNoChain;
+    J.active = chain != kNoChain;
+    J.seg = J.active ? chain / CH : A.S.segBegin;
+    J.ch = J.active ? chain % CH : 0;
+    J.na = 4;
+    best = 0;
+    uint32_t p = 0, N = 0;
+    const bool have = seg_packet(A.S, J.seg, p, N);
+    J.p = p;
+    J.N = N;
+    if (J.active && have) {
+        const PacketRec *rec = A.recs + p;
+        J.na = rec->c[J.ch].num;
+        best = (int)rec->mixRes;
+    } else {
+        J.active = false;
+        J.N = 0;
+    }
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
+}
+
+// The class kernels run as separate launches (throughput regime: every kernel fills the machine on its own, plain
+// coalesced stores, no polling).  A fused producer/consumer form of this pass was measured in the latency regime
+// (10 000 packets) and lost to k_final_fused, 0.97 vs 0.77 ms: a third hot loop body in one launch does not fit the
+// instruction cache the workgroups of a CU share.
+//
+// region 0 = the 8-tap class (columns [0, base4)), region 1 = the 4-tap class (columns [base4, nCols)); the grid is
+// sized for the worst case on the host (the class counts live on the device), surplus workgroups leave at once
+template <int DEPTH, int CH, int T, int L>
+__global__ __launch_bounds__(64, 2) void k_class_pred(V1Args A, uint32_t region)
+{
+    __shared__ LmsShared<L> sh;
+    const int lane = threadIdx.x;
+    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
+    constexpr uint32_t C = 64 / L;  // columns per predictor wave
+    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * C;
+    if (col0 >= (region ? nCols : base4)) return;
+    ChainJob J;
+    int best;
+    const uint32_t col = col0 + (uint32_t)(lane / L);
+    class_job<CH>(A, col, region ? base4 + n4 : n8, J, best);
+    const uint32_t N = J.N;
+    int32_t a[T];
+    load_row<L>(J, a, lane);
+    lms_setup<L>(sh, J, best, lane);
+    lms_pass<DEPTH, CH, L, false, true>(sh, A, J, a, N, N, true, A.resC, A.colsPad, col, lane);
+    store_row<L>(J, a, lane);
+}
+
+// final entropy coding of the compacted columns, one lane per chain; LAZY: see golf_put
+template <int CH, bool LAZY>
+__global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits, uint32_t region)
+{
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
+    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * 64u;
+    if (col0 >= (region ? nCols : base4)) return;
+    gol_table_init(recip, lane);
+    __syncthreads();
+    const uint32_t col = col0 + lane;
+    const uint32_t chain = col < (col0 < base4 ? n8 : base4 + n4) ? A.colChain[col] : kNoChain;
+    uint32_t p = 0, N = 0;
+    const bool active = chain != kNoChain && seg_packet(A.S, chain / CH, p, N);
+    PacketRec *rec = A.recs + p;
+    const uint32_t c = active ? chain % CH : 0;
+    const uint32_t n = active ? N : 0;
+    GolF g;
+    golf_reset(g);
+    g.wp = A.bitWords + (active ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + (lane & 1)) * A.wcap;
+    g.wleft = A.wcap - 1;
+    golf_stream<true, true, NoWait, LAZY>(g, n, wave_max(n), chanBits, recip, one_plane(A.resC, A.colsPad, col), NoWait(),
+                                          A.idleFast != 0);
+    golf_flush<true>(g);
+    if (active) rec->c[c].bits = g.bits;
 }
 
 // packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)
@@ -1040,17 +1257,36 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             const bool firstPos = pos == 0;
             if (e) (void)hipEventRecord(e[kStageLms1], sh);
             static const bool fused = [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
-            const bool fuse = fused && H == 1;  // flag words are indexed by workgroup: one sub-batch only
+            // Two regimes (A.thru, set by launch_encode_v1 from the batch size):
+            //  latency     at most ~one predictor wave per SIMD: a stage is as slow as its longest serial chain, so the
+            //              predictor and the coder that trails it share ONE launch (producer/consumer through HBM) and a
+            //              chain gets two lanes;
+            //  throughput  many waves per SIMD: every kernel fills the machine by itself, so the stages run as separate
+            //              launches with plain coalesced stores (the 4-byte write-through hand-off stores of the fused
+            //              launches are one fabric write each and cap them at ~1 TB/s), a chain's taps sit in one lane
+            //              (fewest instructions per chain step), the final pass runs per packet class and the coder
+            //              stores only completed words.  125 000 packets: 15.8 -> ~11 ms.
+            const bool thru = A.thru != 0 && H == 1;
+            const bool fuse = fused && H == 1 && !thru;  // flag words are indexed by workgroup: one sub-batch only
             const uint32_t nLms = (nseg * CH + 31) / 32;
             if constexpr (CH == 2) {
+                const bool wide = A.wide81 != 0;
+                const uint32_t nLms1 = wide ? cblocks : nLms;
                 // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
                 if (fuse && A.S.frameSize / 8 < 65536u) {
                     (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
-                    hipLaunchKernelGGL(k_search1_fused<DEPTH>, dim3(nLms + 5 * cblocks), dim3(64), 0, sh, A, nLms, cblocks,
-                                       chanBits);
+                    if (wide)
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sh, A, nLms1,
+                                           cblocks, chanBits);
+                    else
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sh, A, nLms1,
+                                           cblocks, chanBits);
                     if (e) (void)hipEventRecord(e[kStageGol1], sh);
                 } else {
-                    hipLaunchKernelGGL(k_lms_search1<DEPTH>, dim3(nLms), dim3(64), 0, sh, A);
+                    if (wide)
+                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 8, 1>), dim3(nLms1), dim3(64), 0, sh, A);
+                    else
+                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 4, 2>), dim3(nLms1), dim3(64), 0, sh, A);
                     if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
                     if (e) (void)hipEventRecord(e[kStageGol1], sh);
                     hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sh, A, chanBits);
@@ -1067,7 +1303,28 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sh, A, chanBits);
             hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
             if (e) (void)hipEventRecord(e[kStageLms3], sh);
-            if (fuse) {
+            if (thru) {
+                // final pass by packet class: compact the packets that still need it (k_class_count, k_class_assign), then per class the
+                // lane mapping that fits it — escaped packets cost nothing, all-4-tap packets run 64 chains per wave
+                const uint32_t cwaves = (((nseg * CH + 63) & ~63u) + 64) / 64;  // worst case per region, + the padding
+                uint32_t *blockCnt = (uint32_t *)(A.cls + 1);
+                hipLaunchKernelGGL(k_class_count<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sh, A, blockCnt);
+                hipLaunchKernelGGL(k_class_assign<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sh, A, blockCnt);
+                // the two classes are independent from here on: predictor -> coder of the 4-tap class on a side stream beside
+                // those of the 8-tap class.  Each kernel alone leaves the machine unevenly filled (a few thousand waves of
+                // ~1 ms each on 1024 SIMDs, LDS-limited to 6 predictor waves per CU); side by side the light coder waves
+                // of one class fill what the predictor waves of the other cannot use.
+                hipStream_t s2 = vs.side[0];
+                (void)hipEventRecord(vs.fork, sh);
+                (void)hipStreamWaitEvent(s2, vs.fork, 0);
+                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sh, A, 0u);
+                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
+                if (e) (void)hipEventRecord(e[kStageGol3], sh);
+                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sh, A, chanBits, 0u);
+                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                (void)hipEventRecord(vs.join[0], s2);
+                (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+            } else if (fuse) {
                 (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
                 hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sh, A, nLms, chanBits);
                 if (e) (void)hipEventRecord(e[kStageGol3], sh);
@@ -1129,10 +1386,18 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         static const int forced = [] { const char *v = getenv("ALAC_HIP_IDLEFAST"); return v ? atoi(v) : -1; }();
         const uint64_t chains = (uint64_t)ea.numSegments * channels;
         A.idleFast = forced >= 0 ? (uint32_t)forced : (chains <= 65536 ? 1u : 0u);
+        static const int forced81 = [] { const char *v = getenv("ALAC_HIP_WIDE81"); return v ? atoi(v) : -1; }();
+        static const int forcedThru = [] { const char *v = getenv("ALAC_HIP_THRU"); return v ? atoi(v) : -1; }();
+        A.thru = forcedThru >= 0 ? (uint32_t)forcedThru : (chains > 65536 ? 1u : 0u);
+        A.wide81 = forced81 >= 0 ? (uint32_t)forced81 : A.thru;
+        if (forced < 0) A.idleFast = A.thru ? 0u : 1u;
     }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;
     A.ho = vb.ho;
+    A.cls = (ClassInfo *)vb.cls;
+    A.colChain = vb.colChain;
+    A.colsPad = vb.colsPad;
     {
         static const uint32_t pm = [] {
             const char *v = getenv("ALAC_HIP_PUBFENCE");

@@ -47,14 +47,24 @@ __device__ __forceinline__ void golf_reset(GolF &g)
 // put completes it in place) and the pointer advances when it fills up:
 // no branch, no exec juggling — a lone wave pays ~16-24 cycles per branch, more than the redundant store.
 // Only lanes that own a valid `wp` may call this (the callers sit inside the active-lane regions).
-template <bool WRITE>
+template <bool WRITE, bool LAZY = false>
 __device__ __forceinline__ void golf_put(GolF &g, uint32_t value, uint32_t nbits)
 {
     g.bits += nbits;
     if constexpr (WRITE) {
         g.acc = (g.acc << nbits) | (uint64_t)value;  // callers hand in values already confined to nbits
         g.nacc += nbits;
-        *g.wp = (uint32_t)((g.acc << ((64u - g.nacc) & 63u)) >> 32);
+        // Latency regime (!LAZY): unconditional store — no branch, no exec juggling; the redundant stores are free when
+        // a wave has its SIMD to itself (a predicated store measured +18 % on the whole final launch at 10 000 packets).
+        // Throughput regime (LAZY): each of these stores is 64 lanes in 64 different cache lines, the slowest access
+        // shape there is, and with many waves per CU they queue up behind each other: store only the ~0.4 words per
+        // symbol that are complete (final coder at 125 000 packets: 4.95 -> 2.18 ms).
+        const uint32_t word = (uint32_t)((g.acc << ((64u - g.nacc) & 63u)) >> 32);
+        if constexpr (LAZY) {
+            if (g.nacc >> 5) *g.wp = word;
+        } else {
+            *g.wp = word;
+        }
         const uint32_t adv = min(g.nacc >> 5, g.wleft);  // capacity reached: stay (the packet escapes anyway)
         g.wleft -= adv;
         g.wp += adv;
@@ -72,7 +82,7 @@ __device__ __forceinline__ void golf_flush(GolF &g)
 }
 
 // run-length code (dyn_code, ag_enc.c:115-148) then mb = 0 (:351-358); k is 2..8 here
-template <bool WRITE>
+template <bool WRITE, bool LAZY = false>
 __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
 {
     const uint32_t k = (uint32_t)(lead(g.mb) - 24 + (int32_t)((g.mb + 16u) >> 6));
@@ -89,7 +99,7 @@ __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
         numBits = div + k + 1 - de;
         value = (((1u << div) - 1) << (numBits - div)) + mod + 1 - de;
     }
-    golf_put<WRITE>(g, value, numBits);
+    golf_put<WRITE, LAZY>(g, value, numBits);
     g.mb = 0;
     g.inrun = 0;
 }
@@ -104,7 +114,7 @@ __device__ __forceinline__ void golf_close_run(GolF &g, const uint32_t *recip)
 // Requires bitSize <= 23 so that the escape (9 ones + bitSize raw bits) is one <= 32-bit put.
 // ZZ: the plane already holds the zig-zag image of the residuals (the final predictor pass stores it that way:
 // the map is three instructions per residual here, three per 64 residuals in the predictor's row flush)
-template <bool WRITE, bool CHECKED, bool ZZ = false>
+template <bool WRITE, bool CHECKED, bool ZZ = false, bool LAZY = false>
 __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint32_t bitSize, const uint32_t *recip)
 {
     // (A) ag_enc.c:333-349, on 0/1 flags in vector registers (boolean chains through scalar masks cost a lone
@@ -121,7 +131,7 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
     // (B) one predicated region for the (rare) close
     if (cl) {
         const uint32_t capf = sw;  // closed at a zero: the cap
-        golf_close_run<WRITE>(g, recip);
+        golf_close_run<WRITE, LAZY>(g, recip);
         if (capf) g.zmode = 0;
     }
     // keep (C) ONE copy behind the join: left alone, the compiler threads "mb = 0 after a close" into a second copy
@@ -160,7 +170,7 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
             numBits = 0;
             value = 0;
         }
-        golf_put<WRITE>(g, value, numBits);
+        golf_put<WRITE, LAZY>(g, value, numBits);
         // mb = pb * (n + zmode) + mb - ((pb * mb) >> 9), pb = 40   (:318)
         // (mb can pass 2^24 under sustained large residuals: shifts, not a 24-bit multiply; t2 < 2^24 always)
         // (40 mb) >> 9 == (5 mb) >> 6, and 5 mb < 2^32 for every reachable mb (< 2^26)
@@ -176,12 +186,12 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
 
 // after the last residual: a run that swallowed zeros up to the end is coded now (:351); one that was only
 // just entered by the last residual does not exist in the reference (:328, c < numSamples) and is dropped
-template <bool WRITE>
+template <bool WRITE, bool LAZY = false>
 __device__ __forceinline__ void golf_finish(GolF &g, bool active, const uint32_t *recip)
 {
     const bool close = active && g.inrun && g.nz1 > 1;
     if (__any(close)) {
-        if (close) golf_close_run<WRITE>(g, recip);
+        if (close) golf_close_run<WRITE, LAZY>(g, recip);
     }
     g.inrun = 0;
 }
@@ -224,7 +234,7 @@ __device__ __forceinline__ RowSrc one_plane(const int32_t *plane, uint64_t strid
     return r;
 }
 
-template <bool WRITE, bool ZZ = false, class Need = NoWait>
+template <bool WRITE, bool ZZ = false, class Need = NoWait, bool LAZY = false>
 __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
                                             const uint32_t *recip, const RowSrc &R, Need &&need = Need(),
                                             bool idleFast = true)
@@ -261,12 +271,12 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
     // 3.5 x slower: the 64 KB instruction cache is a hard limit for these kernels).
     auto codeFast = [&](const int32_t (&buf)[B]) {
 #pragma unroll
-        for (int s = 0; s < B; s++) golf_sym<WRITE, false, ZZ>(g, buf[s], true, bitSize, recip);
+        for (int s = 0; s < B; s++) golf_sym<WRITE, false, ZZ, LAZY>(g, buf[s], true, bitSize, recip);
     };
     auto codeChecked = [&](const int32_t (&buf)[B], uint32_t jb) {
         if (jb >= nMaxWave) return;
 #pragma unroll
-        for (int s = 0; s < B; s++) golf_sym<WRITE, true, ZZ>(g, buf[s], jb + s < n, bitSize, recip);
+        for (int s = 0; s < B; s++) golf_sym<WRITE, true, ZZ, LAZY>(g, buf[s], jb + s < n, bitSize, recip);
     };
     const uint32_t fastEnd = (min(nMinWave, nMaxWave) / (3 * B)) * (3 * B);  // whole iterations every lane fully owns
     load(bufA, 0);
@@ -288,7 +298,7 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
         load(bufB, jb + 4 * B);
         codeChecked(bufC, jb + 2 * B);
     }
-    golf_finish<WRITE>(g, n > 0, recip);
+    golf_finish<WRITE, LAZY>(g, n > 0, recip);
 }
 
 // functor form (any per-lane row choice), used only where lanes of one wave disagree about the planes

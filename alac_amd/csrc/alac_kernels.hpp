@@ -87,8 +87,11 @@ struct V1Buffers {
     bool stateInitialised; // rows already hold the caller's initial state
     int32_t *resA, *resB, *resC;
     uint32_t *bits1, *cost2;
-    uint32_t *flags;       // [chains / 32] progress words of the fused final kernel
+    uint32_t *flags;       // progress words of the fused kernels, one per predictor wave (up to chainsPad / 8 + 16)
     uint32_t chainsPad;
+    void *cls;             // ClassInfo of the class-based final pass (alac_encode_v1.hip)
+    uint32_t *colChain;    // [colsPad]
+    uint32_t colsPad;      // chainsPad + 128: row stride of resC
 };
 // side streams and fork/join events for the sub-batch overlap (owned by the context)
 constexpr uint32_t kMaxSubBatches = 8;
