@@ -115,7 +115,7 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.resB = off;
     off = align_up(off + n8 * 2 * lanes * 4, 256);
     // final residuals: columns handed out per packet class (k_class_assign), two regions padded to 64 -> up to 128 spare
-    L.colsPad = (uint32_t)lanes + 128;
+    L.colsPad = (uint32_t)lanes + 256 * kMaxSubBatches;  // every overlapped sub-batch rounds up to whole waves and pads its two regions
     L.resC = off;
     off = align_up(off + ((uint64_t)f->frame_size + 16) * L.colsPad * 4, 256);
     L.bits1 = off;
@@ -127,7 +127,7 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.flags = off;
     off = align_up(off + (lanes / 8 + 16) * 4, 256);  // one word per predictor wave: up to colsPad / 16 + colsPad / 32 of them
     L.cls = off;  // ClassInfo + per-1024-packet class counts of the compaction
-    off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2) * 8, 256);
+    off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2 * kMaxSubBatches) * 8, 256);
     L.colChain = off;
     off = align_up(off + (uint64_t)L.colsPad * 4, 256);
     L.total = off;
@@ -141,8 +141,8 @@ uint32_t sub_batches_requested()
 {
     static const uint32_t v = [] {
         const char *e = getenv("ALAC_HIP_SUBBATCH");
-        int n = e ? atoi(e) : 1;  // measured: no gain at 10k packets, every kernel is bound by one wave's latency
-        if (n < 1) n = 1;
+        int n = e ? atoi(e) : 0;  // 0 = default (v1_sub_batches: one; measured, no gain from more in either regime)
+        if (n < 0) n = 0;
         if (n > (int)kMaxSubBatches) n = kMaxSubBatches;
         return (uint32_t)n;
     }();
@@ -443,7 +443,7 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
     // the stereo batch runs on the context's stream, the mono batch beside it on a second stream (both are bound by
     // the latency of one wave, not by the machine)
     const bool both = M.g[0].count && M.g[1].count;
-    bool side = both && sub_batches_requested() == 1;
+    bool side = both && sub_batches_requested() <= 1;
     if (side && !ctx->mcReady) {
         if (hipStreamCreateWithFlags(&ctx->mcStream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->mcFork, hipEventDisableTiming) != hipSuccess ||
@@ -575,7 +575,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
             ctx->vsReady = true;
         }
         ctx->vs.numSub = sub_batches_requested();
-        if (ev) ctx->profSub.push_back(v1_sub_batches(num_segments, ctx->vs.numSub));
+        if (ev) ctx->profSub.push_back(v1_sub_batches(num_segments, ctx->vs.numSub, fmt->num_channels));
         // packets per segment: the pipeline runs once per packet position (a chained segment is serial)
         uint32_t maxSeg = 1;
         if (d_seg_first) {

@@ -111,17 +111,33 @@ __device__ __forceinline__ void publish_rows(uint32_t *flag, uint32_t rows, int 
 // first they would hold at most their own SIMD slots while spinning with s_sleep, producers fill the remaining slots
 // or follow as consumers time out — the outcome is then an error, never a hang and never silent corruption.
 struct RowWait {
-    const uint32_t *f0, *f1;
+    const uint32_t *f[4];  // producer progress words (a coder wave's 64 chains come from 1, 2 or 4 predictor waves)
+    uint32_t n;
     uint32_t avail, base;
     HandoffCtl ho;
+    // producers first .. first + count - 1, of which only those below `limit` exist
+    __device__ __forceinline__ void producers(const uint32_t *flags, uint32_t first, uint32_t count, uint32_t limit)
+    {
+        n = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            f[i] = flags + first;
+            if (i < count && first + i < limit) {
+                f[i] = flags + first + i;
+                n = i + 1;
+            }
+        }
+    }
     __device__ __forceinline__ void operator()(uint32_t rows)
     {
         rows += base;
         if (avail >= rows) return;
         for (uint32_t spins = 0; spins < ho.spinLimit; spins++) {
-            const uint32_t a = __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t b = f1 ? __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-            avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a < b ? a : b));
+            uint32_t m = 0xffffffffu;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (i < n) m = min(m, __hip_atomic_load(f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
             if (avail >= rows) break;
             __builtin_amdgcn_s_sleep(16);
         }
@@ -165,6 +181,7 @@ struct V1Args {
     HandoffCtl ho;         // error word / spin bound / test switch of the in-launch hand-offs
     uint32_t wide81;       // 1: 8-tap rows of the searches run with all taps in one lane (throughput regime)
     uint32_t thru;         // 1: throughput regime (see launch_v1_typed)
+    uint32_t narrow;       // 1: tiny batch: four lanes per chain
     // final pass by packet class (k_class_count, k_class_assign): columns of the residual plane are handed out per class
     ClassInfo *cls;
     uint32_t *colChain;    // [colsPad] chain (segment * CH + channel) of every column, kNoChain for pad columns
@@ -179,8 +196,9 @@ struct V1Args {
 template <int LPC>
 struct LmsShared {
     static constexpr int SLOTS = 64 / LPC;
-    int32_t xs[(SLOTS + 1) * kXsStride];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
-                                          // the residuals as the steps pass (+ one dump row for inert lanes)
+    int32_t xs[(SLOTS + 2) * kXsStride];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
+                                          // the residuals as the steps pass (+ two dump rows: inert lanes, and the u / v
+                                          // of the surplus staging tasks when TASKS is not a multiple of 64)
     int32_t zero[kZeroCells];
     uint32_t pktIdx[SLOTS], pktN[SLOTS];  // per input row: packet and its valid samples
     int32_t rowMix[SLOTS];                // mixRes of the row's packet (this pass)
@@ -361,9 +379,12 @@ __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShare
     for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
         const int idx = it * 64 + lane;
         const int q = idx / GROUPS, grp = idx - q * GROUPS;
-        const int row = q * CH;
+        // 16 chains per wave make 160 tasks: the 32 surplus lanes of the third round load row 0's samples again and
+        // store into the dump rows (the fast paths carry no per-task predicate)
+        const bool real = idx < StageRegs<CH, LPC>::TASKS;
+        const int row = real ? q * CH : 0;
         P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * BPF);
-        P.xs[it] = row * kXsStride + grp * 4;
+        P.xs[it] = (real ? row : StageRegs<CH, LPC>::SLOTS) * kXsStride + grp * 4;
         const int32_t r = CH == 2 ? sh.rowMix[row] : 0;
         P.wl[it] = r ? r : (1 << kMixBits);
         P.wr[it] = r ? (1 << kMixBits) - r : 0;
@@ -676,11 +697,12 @@ __global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
 
 // ---- k_lms_search2: converge passes for numUV = 4 (row 3, one lane per chain) and 8 (row 7, two lanes per
 // chain) in one launch: the first nb3 workgroups take the 4-tap rows (codec/ALACEncoder.cu:420-431; mono :881-893)
-template <int DEPTH, int CH, int LPC>
+// RS = 0: row 3 (numUV = 4), RS = 1: row 7 (numUV = 8); T taps per lane x LPC lanes per chain
+template <int DEPTH, int CH, int RS, int T, int LPC>
 __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane)
 {
     constexpr int SLOTS = 64 / LPC;
-    constexpr int rs = LPC == 2 ? 1 : 0;
+    constexpr int rs = RS;
     ChainJob J;
     const uint32_t chain = A.S.segBegin * CH + block * SLOTS + lane / LPC;
     J.seg = chain / CH;
@@ -688,7 +710,7 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
     J.active = seg_packet(A.S, J.seg, J.p, J.N);
     J.na = rs ? 8 : 4;
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + rs * 16;
-    int32_t a[4];
+    int32_t a[T];
     load_row<LPC>(J, a, lane);
     const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
     lms_setup<LPC>(sh, J, best, lane);
@@ -705,17 +727,18 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
     store_row<LPC>(J, a, lane);
 }
 
-template <int DEPTH, int CH>
+// <T3, L3>: mapping of the 4-tap rows, <T7, L7>: of the 8-tap rows (<4, 1> and <4, 2>; <2, 2> and <2, 4> for tiny batches)
+template <int DEPTH, int CH, int T3 = 4, int L3 = 1, int T7 = 4, int L7 = 2>
 __global__ __launch_bounds__(64) void k_lms_search2(V1Args A, uint32_t nb3)
 {
     __shared__ union {
-        LmsShared<1> s1;
-        LmsShared<2> s2;
+        LmsShared<L3> s1;
+        LmsShared<L7> s2;
     } sh;
     if (blockIdx.x < nb3)
-        search2_body<DEPTH, CH, 1>(sh.s1, A, blockIdx.x, threadIdx.x);
+        search2_body<DEPTH, CH, 0, T3, L3>(sh.s1, A, blockIdx.x, threadIdx.x);
     else
-        search2_body<DEPTH, CH, 2>(sh.s2, A, blockIdx.x - nb3, threadIdx.x);
+        search2_body<DEPTH, CH, 1, T7, L7>(sh.s2, A, blockIdx.x - nb3, threadIdx.x);
 }
 
 // ---- k_lms_final: final pass with the chosen row (codec/ALACEncoder.cu:505-532, :941)
@@ -797,8 +820,7 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
         golf_reset(g);
         // the 64 chains of this wave come from 64 / (64 / L) = L producer waves
         RowWait wait;
-        wait.f0 = A.flags + L * w;
-        wait.f1 = (L == 2 && 2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
+        wait.producers(A.flags, L * w, L, nLms);
         wait.avail = 0;
         wait.base = r << 16;
         wait.ho = A.ho;
@@ -932,15 +954,15 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
 // two producers through the residual plane, 256 samples behind.  Both kinds are single-wave workgroups and
 // together (625 + 313 at 10k packets) still fit one per SIMD, so the ~1.0 ms and ~1.3 ms of the two stages
 // overlap instead of adding up.
-template <int DEPTH, int CH>
+template <int DEPTH, int CH, int T = 4, int L = 2>
 __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits)
 {
-    __shared__ LmsShared<2> sh;
+    __shared__ LmsShared<L> sh;
     __shared__ uint32_t recip[17];
     const int lane = threadIdx.x;
     if (blockIdx.x < nLms) {
         ChainJob J;
-        const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 32u + lane / 2;
+        const uint32_t chain = A.S.segBegin * CH + blockIdx.x * (64u / L) + lane / L;
         J.seg = chain / CH;
         J.ch = chain % CH;
         J.active = seg_packet(A.S, J.seg, J.p, J.N);
@@ -954,12 +976,12 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
             if (rec->escape) J.active = false;
         }
         J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
-        int32_t a[4];
-        load_row<2>(J, a, lane);
-        lms_setup<2>(sh, J, best, lane);
+        int32_t a[T];
+        load_row<L>(J, a, lane);
+        lms_setup<L>(sh, J, best, lane);
         uint32_t *flag = A.flags + blockIdx.x;
-        lms_pass<DEPTH, CH, 2, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
-        store_row<2>(J, a, lane);
+        lms_pass<DEPTH, CH, L, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
+        store_row<L>(J, a, lane);
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come (also covers inactive waves)
     } else {
         gol_table_init(recip, lane);
@@ -979,9 +1001,8 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         golf_reset(g);
         g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
         g.wleft = A.wcap - 1;
-            RowWait wait;
-        wait.f0 = A.flags + 2 * w;
-        wait.f1 = (2 * w + 1 < nLms) ? A.flags + 2 * w + 1 : nullptr;
+        RowWait wait;
+        wait.producers(A.flags, L * w, L, nLms);
         wait.avail = 0;
         wait.base = 0;
         wait.ho = A.ho;
@@ -1232,9 +1253,7 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
     // Sub-batches: the predictor kernels saturate VALU issue while the Golomb kernels are bound by the
     // latency of one serial chain per lane and leave most SIMDs idle, so sub-batch h+1 starts its predictor
     // kernels as soon as sub-batch h has finished its first one and the two kinds of kernel overlap.
-    uint32_t H = vs.numSub;
-    if (H < 1) H = 1;
-    while (H > 1 && nsegAll < H * 256) H >>= 1;                 // not worth splitting small batches
+    const uint32_t H = v1_sub_batches(nsegAll, vs.numSub, CH);
     uint32_t per = ((nsegAll + H - 1) / H + 63) & ~63u;         // whole waves per sub-batch
     if (H > 1) (void)hipEventRecord(vs.fork, st);
     for (uint32_t h = 0; h < H; h++) {
@@ -1242,6 +1261,11 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
         A.S.segBegin = h * per;
         A.S.segEnd = (h + 1) * per < nsegAll ? (h + 1) * per : nsegAll;
         if (A.S.segBegin >= A.S.segEnd) break;
+        // class layout of the final pass: every sub-batch compacts into its own window of columns
+        A.cls = A0.cls + h;
+        A.colChain = A0.colChain + (uint64_t)h * (per * CH + 128);
+        A.resC = A0.resC + (uint64_t)h * (per * CH + 128);
+        uint32_t *blockCnt = (uint32_t *)(A0.cls + kMaxSubBatches) + 2 * (A.S.segBegin / 1024 + h);
         const uint32_t nseg = A.S.segEnd - A.S.segBegin;
         const uint32_t cblocks = (nseg * CH + 63) / 64;
         hipStream_t sh = h == 0 ? st : vs.side[h - 1];
@@ -1266,14 +1290,24 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             //              launches are one fabric write each and cap them at ~1 TB/s), a chain's taps sit in one lane
             //              (fewest instructions per chain step), the final pass runs per packet class and the coder
             //              stores only completed words.  125 000 packets: 15.8 -> ~11 ms.
-            const bool thru = A.thru != 0 && H == 1;
+            const bool thru = A.thru != 0;
             const bool fuse = fused && H == 1 && !thru;  // flag words are indexed by workgroup: one sub-batch only
             const uint32_t nLms = (nseg * CH + 31) / 32;
+            // Tiny batches (a single chained file, a few hundred files side by side): the chains do not even fill one
+            // wave per SIMD at 16 chains per wave, so a chain gets FOUR lanes x 2 taps (two lanes for the 4-tap rows of the
+            // search) — ~44 instead of ~62 instructions per wave step on every serial chain of the packet position.
+            const bool narrow = A.narrow != 0 && fuse;
+            const uint32_t nLms16 = (nseg * CH + 15) / 16;
             if constexpr (CH == 2) {
                 const bool wide = A.wide81 != 0;
                 const uint32_t nLms1 = wide ? cblocks : nLms;
                 // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
-                if (fuse && A.S.frameSize / 8 < 65536u) {
+                if (fuse && narrow && A.S.frameSize / 8 < 65536u) {
+                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sh);
+                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 2, 4>), dim3(nLms16 + 5 * cblocks), dim3(64), 0, sh, A, nLms16, cblocks,
+                                       chanBits);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sh);
+                } else if (fuse && A.S.frameSize / 8 < 65536u) {
                     (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
                     if (wide)
                         hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sh, A, nLms1,
@@ -1297,7 +1331,10 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             }
             if (e) (void)hipEventRecord(e[kStageLms2], sh);
             const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
-            hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sh, A, nb3);
+            if (narrow)
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sh, A, nb7);
+            else
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sh, A, nb3);
             if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
             if (e) (void)hipEventRecord(e[kStageGol2], sh);
             hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sh, A, chanBits);
@@ -1307,23 +1344,32 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
                 // final pass by packet class: compact the packets that still need it (k_class_count, k_class_assign), then per class the
                 // lane mapping that fits it — escaped packets cost nothing, all-4-tap packets run 64 chains per wave
                 const uint32_t cwaves = (((nseg * CH + 63) & ~63u) + 64) / 64;  // worst case per region, + the padding
-                uint32_t *blockCnt = (uint32_t *)(A.cls + 1);
                 hipLaunchKernelGGL(k_class_count<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sh, A, blockCnt);
                 hipLaunchKernelGGL(k_class_assign<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sh, A, blockCnt);
                 // the two classes are independent from here on: predictor -> coder of the 4-tap class on a side stream beside
                 // those of the 8-tap class.  Each kernel alone leaves the machine unevenly filled (a few thousand waves of
                 // ~1 ms each on 1024 SIMDs, LDS-limited to 6 predictor waves per CU); side by side the light coder waves
                 // of one class fill what the predictor waves of the other cannot use.
-                hipStream_t s2 = vs.side[0];
-                (void)hipEventRecord(vs.fork, sh);
-                (void)hipStreamWaitEvent(s2, vs.fork, 0);
+                // (with overlapped sub-batches the other sub-batch plays that part and the side streams are theirs)
+                const bool two = H == 1;
+                hipStream_t s2 = two ? vs.side[0] : sh;
+                if (two) {
+                    (void)hipEventRecord(vs.fork, sh);
+                    (void)hipStreamWaitEvent(s2, vs.fork, 0);
+                }
                 hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sh, A, 0u);
                 hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
                 if (e) (void)hipEventRecord(e[kStageGol3], sh);
                 hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sh, A, chanBits, 0u);
                 hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
-                (void)hipEventRecord(vs.join[0], s2);
-                (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                if (two) {
+                    (void)hipEventRecord(vs.join[0], s2);
+                    (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                }
+            } else if (narrow) {
+                (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sh);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sh, A, nLms16, chanBits);
+                if (e) (void)hipEventRecord(e[kStageGol3], sh);
             } else if (fuse) {
                 (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
                 hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sh, A, nLms, chanBits);
@@ -1348,10 +1394,23 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
     launch_scan_pack(DEPTH, CH, A0.packetBytes, pa, numPackets, st, evt, false);
 }
 
-uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested)
+// chains beyond what one 2-lane predictor wave per SIMD holds (1024 SIMDs x 32 chains x 2): throughput regime
+bool v1_throughput_regime(uint32_t numSegments, uint32_t channels)
 {
-    uint32_t H = requested < 1 ? 1 : requested;
-    while (H > 1 && numSegments < H * 256) H >>= 1;
+    static const int forcedThru = [] { const char *v = getenv("ALAC_HIP_THRU"); return v ? atoi(v) : -1; }();
+    if (forcedThru >= 0) return forcedThru != 0;
+    return (uint64_t)numSegments * (channels > 2 ? 2 : channels) > 65536;
+}
+
+// overlapped sub-batches: as requested (ALAC_HIP_SUBBATCH), one by default.  Measured at 125 000 packets in the
+// throughput regime: 1 -> 11.6 ms, 2 -> 12.3 ms, 4 -> 13.6 ms (the halves' kernels get in each other's way more than
+// they fill each other's tails; the two packet classes of the final pass side by side do that job better); at 10 000
+// packets every kernel is bound by one wave's latency and splitting gains nothing either.
+uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels)
+{
+    (void)channels;
+    uint32_t H = requested ? requested : 1u;
+    while (H > 1 && numSegments < H * 256) H >>= 1;  // not worth splitting small batches
     return H;
 }
 
@@ -1387,10 +1446,11 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         const uint64_t chains = (uint64_t)ea.numSegments * channels;
         A.idleFast = forced >= 0 ? (uint32_t)forced : (chains <= 65536 ? 1u : 0u);
         static const int forced81 = [] { const char *v = getenv("ALAC_HIP_WIDE81"); return v ? atoi(v) : -1; }();
-        static const int forcedThru = [] { const char *v = getenv("ALAC_HIP_THRU"); return v ? atoi(v) : -1; }();
-        A.thru = forcedThru >= 0 ? (uint32_t)forcedThru : (chains > 65536 ? 1u : 0u);
+        A.thru = v1_throughput_regime(ea.numSegments, channels) ? 1u : 0u;
         A.wide81 = forced81 >= 0 ? (uint32_t)forced81 : A.thru;
         if (forced < 0) A.idleFast = A.thru ? 0u : 1u;
+        static const int forcedNarrow = [] { const char *v = getenv("ALAC_HIP_NARROW"); return v ? atoi(v) : -1; }();
+        A.narrow = forcedNarrow >= 0 ? (uint32_t)forcedNarrow : (chains <= 4096 ? 1u : 0u);
     }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;
@@ -1417,9 +1477,11 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         break;
     switch (depth) {
         V1_CASE(16)
+#ifndef ALAC_DEV_DEPTH16  // development builds: 16-bit only (make EXTRA=-DALAC_DEV_DEPTH16), a quarter of the compile time
         V1_CASE(20)
         V1_CASE(24)
         V1_CASE(32)
+#endif
     default: return hipErrorInvalidValue;
     }
 #undef V1_CASE

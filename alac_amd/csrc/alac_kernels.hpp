@@ -91,18 +91,19 @@ struct V1Buffers {
     uint32_t chainsPad;
     void *cls;             // ClassInfo of the class-based final pass (alac_encode_v1.hip)
     uint32_t *colChain;    // [colsPad]
-    uint32_t colsPad;      // chainsPad + 128: row stride of resC
+    uint32_t colsPad;      // chainsPad + 128 per possible sub-batch: row stride of resC
 };
 // side streams and fork/join events for the sub-batch overlap (owned by the context)
 constexpr uint32_t kMaxSubBatches = 8;
 struct V1Streams {
-    uint32_t numSub;   // requested sub-batches (1 = no overlap)
+    uint32_t numSub;   // requested sub-batches (1 = no overlap, 0 = automatic)
     uint32_t maxSub;   // slots reserved in the stage-event array (= kMaxSubBatches)
     hipStream_t side[kMaxSubBatches - 1];
     hipEvent_t fork, stagger[kMaxSubBatches - 1], join[kMaxSubBatches - 1];
 };
 // sub-batches actually used for a batch of numSegments segments
-uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested);
+uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels);
+bool v1_throughput_regime(uint32_t numSegments, uint32_t channels);
 // ev (nullable): (maxSub + 1) blocks of kNumStages + 1 events; block h < maxSub = sub-batch h's predictor /
 // Golomb stages on its own stream, block maxSub = finalize + scan + pack on the caller's stream
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,

@@ -87,12 +87,19 @@ def baseline_metric():
         return "encode Msamples/s (bit-exact) 44.1kHz/16-bit stereo, 1/2/4/8 GPU"
 
 
-def kernel_symbol(stage, fused, depth):
+def kernel_symbol(stage, fused, depth, thru=False):
     """HIP kernel behind a bench stage name (what rocprofv3's kernel stats list)."""
     if stage == "lms_final" and any(f.startswith("lms_final") for f in fused):
-        return f"k_final_fused<{depth}, 2> (final pc_block pass || final dyn_comp, one launch)"
+        return f"k_final_fused<{depth}, 2, 4, 2> (final pc_block pass || final dyn_comp, one launch)"
     if stage == "lms_search1" and any(f.startswith("lms_search1") for f in fused):
-        return f"k_search1_fused<{depth}> (mixRes search passes || their dyn_comp counts, one launch)"
+        return f"k_search1_fused<{depth}, 4, 2> (mixRes search passes || their dyn_comp counts, one launch)"
+    if thru:  # throughput regime: separate launches, final pass per packet class on two streams
+        return {"lms_search1": f"k_lms_search1<{depth}, 8, 1>", "golomb_count1": "k_gol_count1<2>",
+                "lms_search2": f"k_lms_search2<{depth}, 2, 4, 1, 4, 2>", "golomb_count2": "k_gol_count2<2>",
+                "lms_final": f"k_class_pred<{depth}, 2, 8, 1> || k_class_pred<{depth}, 2, 4, 1> (final pc_block pass per packet "
+                             "class, side by side; + k_class_count / k_class_assign)",
+                "golomb_final": "k_class_coder<2, true> (both classes; the event interval also covers the join of the side stream)",
+                "finalize_scan": "k_finalize + k_scan_sizes", "pack": "k_pack"}.get(stage, stage)
     return {"lms_search1": "k_lms_search1", "golomb_count1": "k_gol_count1", "lms_search2": "k_lms_search2",
             "golomb_count2": "k_gol_count2", "lms_final": "k_lms_final", "golomb_final": "k_gol_final",
             "finalize_scan": "k_finalize + k_scan_sizes", "pack": "k_pack"}.get(stage, stage)
@@ -329,7 +336,8 @@ def main():
         # instruction mix of the same command, tools/pmc_instruction_mix.sh -> profiles/instruction_mix.json)
         issue = None
         ipath = os.path.join(ROOT, "profiles", "instruction_mix.json")
-        sym = kernel_symbol(dom, fused, args.bit_depth)
+        thru = B * 2 > 65536 and not fused  # alac_encode_v1.hip v1_throughput_regime
+        sym = kernel_symbol(dom, fused, args.bit_depth, thru)
         if os.path.exists(ipath) and ms_dom > 0 and B == 10000 and args.bit_depth == 16:
             try:
                 with open(ipath) as f:
@@ -377,6 +385,8 @@ def main():
             "output_bytes_per_step_per_gpu": total_bytes,
             "stages": stages,
             "fused_launches": fused,
+            "regime": ("throughput: separate launches, 8 taps per lane in the searches, final pass per packet class, lazy word "
+                       "stores" if thru else "latency: producer/consumer launches, two lanes per chain"),
             "calls_timed": calls,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -17,6 +17,7 @@ STAGE_OF = [
     ("k_search1_fused", "lms_search1"), ("k_lms_search1", "lms_search1"), ("k_gol_count1", "golomb_count1"),
     ("k_lms_search2", "lms_search2"), ("k_gol_count2", "golomb_count2"),
     ("k_final_fused", "lms_final"), ("k_lms_final", "lms_final"), ("k_gol_final", "golomb_final"),
+    ("k_class_count", "lms_final"), ("k_class_assign", "lms_final"), ("k_class_pred", "lms_final"), ("k_class_coder", "golomb_final"),
     ("k_finalize", "finalize_scan"), ("k_scan_sizes", "finalize_scan"), ("k_pack", "pack"),
 ]
 
