@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64) void k_decode_entropy(DecodeArgs A)
                         resV[(uint64_t)i * rs] = (int32_t)(read_bits(base, nbytes, pos, chanBits) << sh) >> sh;
                 }
                 rec->escape = 1;
+                if ((pos + 7) / 8 > nbytes) status = -50;  // the fixed-width payload ran past the packet (:996-1000)
             }
             rec->numSamples = numSamples;
             lastSamples = numSamples;
