@@ -87,7 +87,7 @@ struct EncLayout {
     uint32_t wcap;
     uint64_t predStride;
     // tap-parallel pipeline: residual planes [sample][stream], decision scratch, working state
-    uint64_t resA, resB, resC, bits1, cost2, state, flags, cls, colChain;
+    uint64_t resA, resB, resC, bits1, cost2, state, flags, rowReady, cls, colChain;
     uint32_t chainsPad, colsPad;
 };
 
@@ -124,8 +124,11 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     off = align_up(off + 2 * lanes * 4, 256);
     L.state = off;
     off = align_up(off + (uint64_t)numSegments * 128, 256);
-    L.flags = off;
-    off = align_up(off + (lanes / 8 + 16) * 4, 256);  // one word per predictor wave: up to colsPad / 16 + colsPad / 32 of them
+    L.flags = off;  // one progress word per predictor wave (up to lanes / 16), twice: search and final launch of
+                    // consecutive packet positions of a chained batch run side by side
+    off = align_up(off + 2 * (lanes / 8 + 16) * 4, 256);
+    L.rowReady = off;
+    off = align_up(off + lanes * 4, 256);
     L.cls = off;  // ClassInfo + per-1024-packet class counts of the compaction
     off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2 * kMaxSubBatches) * 8, 256);
     L.colChain = off;
@@ -599,6 +602,8 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
         vb.bits1 = (uint32_t *)(ws + L.bits1);
         vb.cost2 = (uint32_t *)(ws + L.cost2);
         vb.flags = (uint32_t *)(ws + L.flags);
+        vb.flagsF = vb.flags + (L.chainsPad / 8 + 16);
+        vb.rowReady = (uint32_t *)(ws + L.rowReady);
         vb.chainsPad = L.chainsPad;
         vb.cls = ws + L.cls;
         vb.colChain = (uint32_t *)(ws + L.colChain);

@@ -182,6 +182,10 @@ struct V1Args {
     uint32_t wide81;       // 1: 8-tap rows of the searches run with all taps in one lane (throughput regime)
     uint32_t thru;         // 1: throughput regime (see launch_v1_typed)
     uint32_t narrow;       // 1: tiny batch: four lanes per chain
+    // chained tiny batches: the mixRes search of packet position p + 1 runs beside the final pass of position p
+    uint32_t *rowReady;    // [chains] position + 1 whose final pass has stored the chain's 8-tap row (0: not used)
+    uint32_t *flagsF;      // progress words of the final launch (the search launch next to it uses `flags`)
+    uint32_t *ovRowReady, *ovFlagsF;  // the buffers the launcher switches the two above to when it overlaps positions
     // final pass by packet class (k_class_count, k_class_assign): columns of the residual plane are handed out per class
     ClassInfo *cls;
     uint32_t *colChain;    // [colsPad] chain (segment * CH + channel) of every column, kNoChain for pad columns
@@ -671,6 +675,27 @@ __device__ __forceinline__ void search1_predictor(LmsShared<L> &sh, const V1Args
     J.active = seg_packet(A.S, J.seg, J.p, J.N);
     J.na = 8;
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
+    if (A.rowReady && A.S.pos > 0) {
+        // Chained batch with overlapped positions: this launch runs BESIDE the final pass of the previous packet position.
+        // A chain whose previous packet runs its final pass on the 8-tap row must wait until that pass has stored the row;
+        // one that chose 4 taps (or escaped) left the row final when its search ended, before this launch began.
+        bool wait = false;
+        if (J.active) {
+            const PacketRec *prev = A.recs + (J.p - 1);
+            wait = !prev->escape && prev->c[J.ch].num == 8;
+        }
+        bool seen = false;
+        for (uint32_t spins = 0; spins < A.ho.spinLimit; spins++) {
+            const uint32_t r = wait ? __hip_atomic_load(A.rowReady + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(r >= A.S.pos)) {
+                seen = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!seen && A.ho.err && lane == 0) __hip_atomic_store(A.ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     int32_t a[T];
     load_row<L>(J, a, lane);
     const uint32_t n8 = J.N / 8;
@@ -979,9 +1004,17 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         int32_t a[T];
         load_row<L>(J, a, lane);
         lms_setup<L>(sh, J, best, lane);
-        uint32_t *flag = A.flags + blockIdx.x;
+        uint32_t *flag = A.flagsF + blockIdx.x;
         lms_pass<DEPTH, CH, L, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
         store_row<L>(J, a, lane);
+        if (A.rowReady) {
+            // the next position's search may be waiting for this row (see search1_predictor)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (J.active && J.na == 8 && lane % L == 0 && !A.ho.lose)
+                __hip_atomic_store(A.rowReady + chain, A.S.pos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come (also covers inactive waves)
     } else {
         gol_table_init(recip, lane);
@@ -1002,7 +1035,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
         g.wleft = A.wcap - 1;
         RowWait wait;
-        wait.producers(A.flags, L * w, L, nLms);
+        wait.producers(A.flagsF, L * w, L, nLms);
         wait.avail = 0;
         wait.base = 0;
         wait.ho = A.ho;
@@ -1275,11 +1308,27 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
         }
         // stage events: sub-batch h records into ev + h * (kNumStages + 1) on its own stream
         hipEvent_t *evh = ev ? ev + (size_t)h * (kNumStages + 1) : nullptr;
+        // Chained tiny batches (a file = one chain of packets): packet position p + 1's mixRes search only needs the 8-tap
+        // rows, which position p leaves alone once its own search is over unless it runs its FINAL pass on them — so the
+        // positions alternate between two streams, the search launch of p + 1 starts when decide2 of p has run and its
+        // predictor waves wait, per chain, for rows that p's final pass still owns (rowReady).  The rest of p + 1 waits for
+        // p's final pass.  58-75 % of packets choose 4 taps on both channels: their successor's search (a third of a
+        // position's serial chain) disappears behind the final pass.
+        static const bool ovEnv = [] { const char *v = getenv("ALAC_HIP_OVERLAP_POS"); return !(v && v[0] == '0'); }();
+        const bool overlap = ovEnv && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
+                             A.S.frameSize / 8 < 65536u && [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
+        if (overlap) {
+            A.rowReady = A0.ovRowReady;
+            A.flagsF = A0.ovFlagsF;
+            (void)hipMemsetAsync(A.rowReady, 0, (size_t)A0.chainsPad * 4, sh);
+        }
         for (uint32_t pos = 0; pos < maxSegPackets; pos++) {
             A.S.pos = pos;
+            hipStream_t sp = (overlap && (pos & 1)) ? vs.side[0] : sh;
+            if (overlap && pos > 0) (void)hipStreamWaitEvent(sp, vs.stagger[(pos - 1) & 1], 0);  // decide2 of pos - 1
             hipEvent_t *e = (evh && pos + 1 == maxSegPackets) ? evh : nullptr;
             const bool firstPos = pos == 0;
-            if (e) (void)hipEventRecord(e[kStageLms1], sh);
+            if (e) (void)hipEventRecord(e[kStageLms1], sp);
             static const bool fused = [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
             // Two regimes (A.thru, set by launch_encode_v1 from the batch size):
             //  latency     at most ~one predictor wave per SIMD: a stage is as slow as its longest serial chain, so the
@@ -1303,49 +1352,51 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
                 const uint32_t nLms1 = wide ? cblocks : nLms;
                 // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
                 if (fuse && narrow && A.S.frameSize / 8 < 65536u) {
-                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sh);
-                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 2, 4>), dim3(nLms16 + 5 * cblocks), dim3(64), 0, sh, A, nLms16, cblocks,
+                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
+                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 2, 4>), dim3(nLms16 + 5 * cblocks), dim3(64), 0, sp, A, nLms16, cblocks,
                                        chanBits);
-                    if (e) (void)hipEventRecord(e[kStageGol1], sh);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else if (fuse && A.S.frameSize / 8 < 65536u) {
-                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
+                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
                     if (wide)
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sh, A, nLms1,
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
                                            cblocks, chanBits);
                     else
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sh, A, nLms1,
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
                                            cblocks, chanBits);
-                    if (e) (void)hipEventRecord(e[kStageGol1], sh);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else {
                     if (wide)
-                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 8, 1>), dim3(nLms1), dim3(64), 0, sh, A);
+                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 8, 1>), dim3(nLms1), dim3(64), 0, sp, A);
                     else
-                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 4, 2>), dim3(nLms1), dim3(64), 0, sh, A);
-                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
-                    if (e) (void)hipEventRecord(e[kStageGol1], sh);
-                    hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sh, A, chanBits);
+                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 4, 2>), dim3(nLms1), dim3(64), 0, sp, A);
+                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
+                    hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sp, A, chanBits);
                 }
-                hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
+                hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             } else if (e) {
-                (void)hipEventRecord(e[kStageGol1], sh);
+                (void)hipEventRecord(e[kStageGol1], sp);
             }
-            if (e) (void)hipEventRecord(e[kStageLms2], sh);
+            if (overlap && pos > 0) (void)hipStreamWaitEvent(sp, vs.join[(pos - 1) & 1], 0);  // final pass of pos - 1
+            if (e) (void)hipEventRecord(e[kStageLms2], sp);
             const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
             if (narrow)
-                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sh, A, nb7);
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
             else
-                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sh, A, nb3);
-            if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sh);
-            if (e) (void)hipEventRecord(e[kStageGol2], sh);
-            hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sh, A, chanBits);
-            hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sh, A);
-            if (e) (void)hipEventRecord(e[kStageLms3], sh);
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
+            if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+            if (e) (void)hipEventRecord(e[kStageGol2], sp);
+            hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+            hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
+            if (overlap) (void)hipEventRecord(vs.stagger[pos & 1], sp);
+            if (e) (void)hipEventRecord(e[kStageLms3], sp);
             if (thru) {
                 // final pass by packet class: compact the packets that still need it (k_class_count, k_class_assign), then per class the
                 // lane mapping that fits it — escaped packets cost nothing, all-4-tap packets run 64 chains per wave
                 const uint32_t cwaves = (((nseg * CH + 63) & ~63u) + 64) / 64;  // worst case per region, + the padding
-                hipLaunchKernelGGL(k_class_count<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sh, A, blockCnt);
-                hipLaunchKernelGGL(k_class_assign<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sh, A, blockCnt);
+                hipLaunchKernelGGL(k_class_count<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sp, A, blockCnt);
+                hipLaunchKernelGGL(k_class_assign<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sp, A, blockCnt);
                 // the two classes are independent from here on: predictor -> coder of the 4-tap class on a side stream beside
                 // those of the 8-tap class.  Each kernel alone leaves the machine unevenly filled (a few thousand waves of
                 // ~1 ms each on 1024 SIMDs, LDS-limited to 6 predictor waves per CU); side by side the light coder waves
@@ -1354,30 +1405,34 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
                 const bool two = H == 1;
                 hipStream_t s2 = two ? vs.side[0] : sh;
                 if (two) {
-                    (void)hipEventRecord(vs.fork, sh);
+                    (void)hipEventRecord(vs.fork, sp);
                     (void)hipStreamWaitEvent(s2, vs.fork, 0);
                 }
-                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sh, A, 0u);
+                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sp, A, 0u);
                 hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
-                if (e) (void)hipEventRecord(e[kStageGol3], sh);
-                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sh, A, chanBits, 0u);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
                 hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
                 if (two) {
                     (void)hipEventRecord(vs.join[0], s2);
                     (void)hipStreamWaitEvent(sh, vs.join[0], 0);
                 }
             } else if (narrow) {
-                (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sh);
-                hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sh, A, nLms16, chanBits);
-                if (e) (void)hipEventRecord(e[kStageGol3], sh);
+                (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sp, A, nLms16, chanBits);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else if (fuse) {
-                (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sh);
-                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sh, A, nLms, chanBits);
-                if (e) (void)hipEventRecord(e[kStageGol3], sh);
+                (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sp, A, nLms, chanBits);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else {
-                hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sh, A);
-                if (e) (void)hipEventRecord(e[kStageGol3], sh);
-                hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sh, A, chanBits);
+                hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sp, A);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+                hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sp, A, chanBits);
+            }
+            if (overlap) {
+                (void)hipEventRecord(vs.join[pos & 1], sp);
+                if (pos + 1 == maxSegPackets && sp != sh) (void)hipStreamWaitEvent(sh, vs.join[pos & 1], 0);
             }
             if (e) (void)hipEventRecord(e[kStageScan], sh);  // end marker of this sub-batch's last stage
         }
@@ -1454,6 +1509,10 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;
+    A.flagsF = vb.flags;   // one set unless the launcher overlaps positions
+    A.rowReady = nullptr;
+    A.ovRowReady = vb.rowReady;
+    A.ovFlagsF = vb.flagsF;
     A.ho = vb.ho;
     A.cls = (ClassInfo *)vb.cls;
     A.colChain = vb.colChain;

@@ -88,6 +88,8 @@ struct V1Buffers {
     int32_t *resA, *resB, *resC;
     uint32_t *bits1, *cost2;
     uint32_t *flags;       // progress words of the fused kernels, one per predictor wave (up to chainsPad / 8 + 16)
+    uint32_t *flagsF;      // second set (final launch) for the overlapped packet positions of a chained batch
+    uint32_t *rowReady;    // [chainsPad] chained batches: packet position + 1 whose final pass has left the chain's 8-tap row
     uint32_t chainsPad;
     void *cls;             // ClassInfo of the class-based final pass (alac_encode_v1.hip)
     uint32_t *colChain;    // [colsPad]

@@ -253,3 +253,36 @@ def test_cookie_with_unusable_ag_parameters_is_refused(gpu_ctx, oracle):
         ck[field] = value
         with pytest.raises(RuntimeError):
             gpu_ctx.decode(ck, torch.from_numpy(pk).cuda(), offs, 1)
+
+
+@pytest.mark.parametrize("channels", [2, 6])
+def test_decode_through_wrapped_cookies(gpu_ctx, oracle, channels):
+    """the cookie as it appears outside CAF — the legacy 'frma' + 'alac' atom wrapping and the cookie taken
+    out of an MP4 'stsd' sample description (ALACMagicCookieDescription.txt:177-238; ALACDecoder::Init skips the atoms,
+    codec/ALACDecoder.cu:123-134) — must decode on the GPU exactly like the bare cookie."""
+    import torch
+    from container_lib import Container
+    cont = Container()
+    n = 6
+    fmt = alac_amd.make_format(4096, 16, channels)
+    if channels == 2:
+        pcm = alac_amd.synth_pcm(2, n, fmt)
+    else:
+        from oracle_lib import interleave_channels
+        f1, f2 = alac_amd.make_format(4096, 16, 1), alac_amd.make_format(4096, 16, 2)
+        pcm = interleave_channels([(alac_amd.synth_pcm(3, n, f1), 1), (alac_amd.synth_pcm(4, n, f2), 2),
+                                   (alac_amd.synth_pcm(5, n, f2), 2), (alac_amd.synth_pcm(6, n, f1), 1)], 16)
+    enc = oracle.encoder(4096, 16, channels)
+    stream, sizes = enc.encode_stream(pcm, n * 4096, 1)
+    bare = bytes(enc.cookie())
+    legacy = cont.cookie(0, bare)                      # 'frma' + 'alac' info atoms + terminator around the config
+    from_mp4 = cont.parse_stsd(cont.build_stsd(bare, channels, 16, 44100))[0]
+    assert from_mp4 == bare and len(legacy) == len(bare) + 32
+    d_stream = torch.from_numpy(stream).cuda()
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])).cuda()
+    for ck in (bare, legacy, legacy[12:], from_mp4):
+        out, ns, st, f2 = gpu_ctx.decode(np.frombuffer(ck, np.uint8), d_stream, offs, n)
+        gpu_ctx.synchronize()
+        assert (f2.frame_size, f2.bit_depth, f2.num_channels, f2.sample_rate) == (4096, 16, channels, 44100)
+        assert int(st.abs().sum()) == 0 and int(ns.sum()) == n * 4096
+        assert np.array_equal(out.cpu().numpy(), pcm)
