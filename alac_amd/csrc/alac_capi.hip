@@ -96,7 +96,7 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     EncLayout L;
     // escape size bounds what a compressed element may use (codec/ALACEncoder.cu:459,:538)
     const uint64_t escapeBits = (uint64_t)f->frame_size * f->bit_depth * f->num_channels + 32 + 16;
-    L.wcap = (uint32_t)((escapeBits + 31) / 32 + 4);
+    L.wcap = (uint32_t)(((escapeBits + 31) / 32 + 4 + 3) & ~3ull);  // a multiple of 4 words: 16-byte aligned channel slots
     const uint64_t lanes = align_up((uint64_t)numSegments * f->num_channels, 64);
     L.predStride = lanes;
     uint64_t off = 0;

@@ -37,14 +37,18 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-constexpr int kTile = 64;         // predictor steps per LDS tile
 constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; 12 keeps
                                   // the 16-byte PCM loads of the staging aligned)
-constexpr int kRowLen = kHist + kTile + 4;  // 80 staged samples per row
-constexpr int kXsStride = 89;     // dwords per input row: >= kRowLen + 9 (operand prefetch over-read / warm-up parking), odd
-// Residuals are written IN PLACE: res[j] goes to cell j - j0 of the chain's input row, which held x[j - kHist]; the oldest
-// input any later step (or operand prefetch) still reads is x[j - 1 - 8], four cells further on.  One LDS array per
-// wave: 11.7 KB for 32 chains, 23 KB for 64 — twice the waves per CU a separate residual tile allowed.
+// Tile geometry by lanes per chain.  One lane per chain = 64 chains per wave: a 64-step tile would take 23 KB of LDS per
+// wave (6 waves per CU); 32 steps take 14.8 KB (10 per CU).  These mappings run where many waves share a SIMD (throughput
+// regime) or off the critical path (the 4-tap rows of the search), so the extra tile boundaries are cheap there.
+template <int LPC>
+struct Geo {
+    static constexpr int TILE = LPC == 1 ? 32 : 64;   // predictor steps per LDS tile
+    static constexpr int ROWLEN = kHist + TILE + 4;   // staged samples per row (80 / 48)
+    static constexpr int STRIDE = ROWLEN + 9;         // dwords per input row: + 9 cells of operand prefetch over-read /
+                                                      // warm-up parking; odd (89 / 57)
+};
 constexpr int kZeroCells = 24;    // zeros fed to lanes that hold no active tap
 
 struct SegView {
@@ -200,7 +204,7 @@ struct V1Args {
 template <int LPC>
 struct LmsShared {
     static constexpr int SLOTS = 64 / LPC;
-    int32_t xs[(SLOTS + 2) * kXsStride];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
+    int32_t xs[(SLOTS + 2) * Geo<LPC>::STRIDE];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
                                           // the residuals as the steps pass (+ two dump rows: inert lanes, and the u / v
                                           // of the surplus staging tasks when TASKS is not a multiple of 64)
     int32_t zero[kZeroCells];
@@ -216,7 +220,7 @@ struct LmsShared {
 template <int CH, int LPC>
 struct StageRegs {
     static constexpr int SLOTS = 64 / LPC;
-    static constexpr int TASKS = (SLOTS / CH) * (kRowLen / 4);  // (packet, 4-sample group) pairs
+    static constexpr int TASKS = (SLOTS / CH) * (Geo<LPC>::ROWLEN / 4);  // (packet, 4-sample group) pairs
     static constexpr int ITERS = (TASKS + 63) / 64;
     int32_t v[ITERS][9];  // raw PCM dwords of each task: 4 sample-frames = CH * bytes-per-sample dwords (<= 8), +1 spare
 };
@@ -282,7 +286,7 @@ template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_load(StageRegs<CH, LPC> &R, const LmsShared<LPC> &sh, const uint8_t *pcm,
                                            uint32_t frameBytes, int j0, int lane)
 {
-    constexpr int GROUPS = kRowLen / 4;
+    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
     constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
     const bool vec = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
@@ -307,7 +311,7 @@ template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShared<LPC> &sh, const uint8_t *pcm,
                                             uint32_t frameBytes, int j0, int lane)
 {
-    constexpr int GROUPS = kRowLen / 4;
+    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
     constexpr int SH = 8 * (int)bytes_shifted(DEPTH);
     const bool vec = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
@@ -353,8 +357,8 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            sh.xs[row * kXsStride + grp * 4 + t] = u[t];
-            if constexpr (CH == 2) sh.xs[(row + 1) * kXsStride + grp * 4 + t] = v[t];
+            sh.xs[row * Geo<LPC>::STRIDE + grp * 4 + t] = u[t];
+            if constexpr (CH == 2) sh.xs[(row + 1) * Geo<LPC>::STRIDE + grp * 4 + t] = v[t];
         }
     }
 }
@@ -376,7 +380,7 @@ template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShared<LPC> &sh, const uint8_t *pcm,
                                            uint32_t frameBytes, int lane)
 {
-    constexpr int GROUPS = kRowLen / 4;
+    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
     constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);  // bytes per sample-frame = dwords per 4-frame task
     P.usable = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
@@ -388,7 +392,7 @@ __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShare
         const bool real = idx < StageRegs<CH, LPC>::TASKS;
         const int row = real ? q * CH : 0;
         P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * BPF);
-        P.xs[it] = (real ? row : StageRegs<CH, LPC>::SLOTS) * kXsStride + grp * 4;
+        P.xs[it] = (real ? row : StageRegs<CH, LPC>::SLOTS) * Geo<LPC>::STRIDE + grp * 4;
         const int32_t r = CH == 2 ? sh.rowMix[row] : 0;
         P.wl[it] = r ? r : (1 << kMixBits);
         P.wr[it] = r ? (1 << kMixBits) - r : 0;
@@ -427,7 +431,7 @@ __device__ __forceinline__ void stage_store_fast(const StageRegs<CH, LPC> &R, co
                 const int32_t l = task_sample<DEPTH, 2 * t>(R.v[it]), r = task_sample<DEPTH, 2 * t + 1>(R.v[it]);
                 // codec/matrix_enc.cu:72-99 with the mixRes = 0 case folded into the weights (4 l >> 2 == l)
                 sh.xs[P.xs[it] + t] = (__mul24(P.wl[it], l) + __mul24(P.wr[it], r)) >> kMixBits;
-                sh.xs[P.xs[it] + kXsStride + t] = P.vsel[it] ? l - r : r;
+                sh.xs[P.xs[it] + Geo<LPC>::STRIDE + t] = P.vsel[it] ? l - r : r;
             } else {
                 sh.xs[P.xs[it] + t] = task_sample<DEPTH, t>(R.v[it]);
             }
@@ -540,8 +544,8 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     }
     LaneView V;
     V.feeds = J.active && (T * L.h < J.na);
-    V.row = sh.xs + slot * kXsStride;
-    V.res = V.feeds ? sh.xs + slot * kXsStride : sh.xs + SLOTS * kXsStride;
+    V.row = sh.xs + slot * Geo<LPC>::STRIDE;
+    V.res = V.feeds ? sh.xs + slot * Geo<LPC>::STRIDE : sh.xs + SLOTS * Geo<LPC>::STRIDE;
     V.zero = sh.zero;
     // the lane that flushes slot fs = lane % SLOTS needs that slot's P / stream / activity
     const int fs = lane % SLOTS;
@@ -559,9 +563,9 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     stage_plan<DEPTH, CH, LPC>(SP, sh, A.S.pcm, frameBytes, lane);
     // staged window [j - kHist, j - kHist + kRowLen) inside every packet of the wave -> fast staging of tile j
     const uint32_t nMinRows = wave_min_u32(J.active ? J.N : idleVal);
-    auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + kRowLen) <= nMinRows; };
+    auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + Geo<LPC>::ROWLEN) <= nMinRows; };
     if (runTo > 0) {
-        if (SP.usable && (uint32_t)(kRowLen - kHist) <= nMinRows) {  // first tile inside every packet: no bounds checks
+        if (SP.usable && (uint32_t)(Geo<LPC>::ROWLEN - kHist) <= nMinRows) {  // first tile inside every packet: no bounds checks
             if (head && headMode == 2) {
                 stage_store_fast<DEPTH, CH, LPC>(*head, SP, sh);
             } else {
@@ -574,29 +578,29 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
             stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
         }
     }
-    for (int j0 = 0; j0 < (int)runTo; j0 += kTile) {
-        const bool more = j0 + kTile < (int)runTo;
-        const bool fastNext = more && interior(j0 + kTile);
-        if (fastNext) stage_load_fast<DEPTH, CH, LPC>(R, SP, j0 + kTile);  // in flight under the tile
-        else if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
+    for (int j0 = 0; j0 < (int)runTo; j0 += Geo<LPC>::TILE) {
+        const bool more = j0 + Geo<LPC>::TILE < (int)runTo;
+        const bool fastNext = more && interior(j0 + Geo<LPC>::TILE);
+        if (fastNext) stage_load_fast<DEPTH, CH, LPC>(R, SP, j0 + Geo<LPC>::TILE);  // in flight under the tile
+        else if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + Geo<LPC>::TILE, lane);
         lds_order();
         // warm-up positions of pc_block (dp_enc.c:90, :108-112): pc[0] = in[0], pc[j] = sext(in[j] - in[j-1]).  They are
         // formed from x[0 .. na] BEFORE the steps overwrite those cells with residuals and parked in the row's prefetch
         // over-read cells (kRowLen .. kRowLen + 8, never data), then moved to cells 0 .. na once the tile has run.
         if (store && j0 == 0) {
             for (int pos = lane / SLOTS; pos <= fNa; pos += LPC) {
-                const int32_t *xr = sh.xs + fs * kXsStride + kHist;
-                sh.xs[fs * kXsStride + kRowLen + pos] = pos == 0 ? xr[0] : sext(xr[pos] - xr[pos - 1], 32 - chanBits);
+                const int32_t *xr = sh.xs + fs * Geo<LPC>::STRIDE + kHist;
+                sh.xs[fs * Geo<LPC>::STRIDE + Geo<LPC>::ROWLEN + pos] = pos == 0 ? xr[0] : sext(xr[pos] - xr[pos - 1], 32 - chanBits);
             }
             lds_order();
         }
-        const int jEnd = min(j0 + kTile, (int)((runTo + 7) & ~7u));
+        const int jEnd = min(j0 + Geo<LPC>::TILE, (int)((runTo + 7) & ~7u));
         run_tile<T, LPC>(a, V, L, j0, jEnd, chanBits);
         lds_order();
         if (store) {
             if (j0 == 0) {
                 for (int pos = lane / SLOTS; pos <= fNa; pos += LPC)
-                    sh.xs[fs * kXsStride + pos] = sh.xs[fs * kXsStride + kRowLen + pos];
+                    sh.xs[fs * Geo<LPC>::STRIDE + pos] = sh.xs[fs * Geo<LPC>::STRIDE + Geo<LPC>::ROWLEN + pos];
                 lds_order();
             }
             // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams.  WT (fused launches):
@@ -606,27 +610,27 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *q = v;
             };
-            if ((uint32_t)(j0 + kTile) <= fPmin) {
+            if ((uint32_t)(j0 + Geo<LPC>::TILE) <= fPmin) {
                 // every lane owns every row of the tile: scalar row base + lane column, no predicate, no branch
                 int32_t *tileBase = dst + (uint64_t)j0 * streamStride;
 #pragma unroll
-                for (int it = 0; it < kTile / LPC; it++)
-                    put(tileBase + (uint64_t)(it * LPC) * streamStride + voff, sh.xs[fs * kXsStride + it * LPC + (int)half]);
+                for (int it = 0; it < Geo<LPC>::TILE / LPC; it++)
+                    put(tileBase + (uint64_t)(it * LPC) * streamStride + voff, sh.xs[fs * Geo<LPC>::STRIDE + it * LPC + (int)half]);
             } else {
 #pragma unroll 4
-                for (int it = 0; it < kTile / LPC; it++) {
+                for (int it = 0; it < Geo<LPC>::TILE / LPC; it++) {
                     const int jj = it * LPC + lane / SLOTS;
                     const uint32_t j = (uint32_t)(j0 + jj);
-                    const int32_t v = sh.xs[fs * kXsStride + jj];
+                    const int32_t v = sh.xs[fs * Geo<LPC>::STRIDE + jj];
                     if (j < fP) put(dst + (uint64_t)j * streamStride + fStream, v);
                 }
             }
             // fused final kernel: tell the coder waves how many residual rows are complete (every 4 tiles)
-            if (flag && ((((j0 / kTile) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + kTile, (int)runTo), lane, (A.pubMask >> 31) != 0, A.ho.lose);
+            if (flag && ((((j0 / Geo<LPC>::TILE) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + Geo<LPC>::TILE, (int)runTo), lane, (A.pubMask >> 31) != 0, A.ho.lose);
         }
         lds_order();
         if (fastNext) stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
-        else if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + kTile, lane);
+        else if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + Geo<LPC>::TILE, lane);
     }
 }
 
@@ -699,22 +703,27 @@ __device__ __forceinline__ void search1_predictor(LmsShared<L> &sh, const V1Args
     int32_t a[T];
     load_row<L>(J, a, lane);
     const uint32_t n8 = J.N / 8;
-    StageRegs<2, L> head;
+    // The raw PCM of the first tile is the same for all five passes; keeping it in registers spares each pass the one
+    // load whose latency nothing hides — worth ~50 registers where a wave has its SIMD to itself.  The 64-chain mapping of
+    // the throughput regime would pay for them with its second wave per SIMD and has other waves to hide the load behind.
+    constexpr bool keepHead = L != 1;
+    StageRegs<2, L> headRegs;
+    StageRegs<2, L> *head = keepHead ? &headRegs : nullptr;
     for (int r = 0; r <= kMaxRes; r++) {
         lms_setup<L>(sh, J, r, lane);
         if (flag)
             lms_pass<DEPTH, 2, L, true>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain,
-                                        lane, flag, (uint32_t)r << 16, &head, r == 0 ? 1 : 2);
+                                        lane, flag, (uint32_t)r << 16, head, r == 0 ? 1 : 2);
         else
             lms_pass<DEPTH, 2, L>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
-                                  nullptr, 0, &head, r == 0 ? 1 : 2);
+                                  nullptr, 0, head, r == 0 ? 1 : 2);
     }
     store_row<L>(J, a, lane);
     if (flag) publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);
 }
 
 template <int DEPTH, int T, int L>
-__global__ __launch_bounds__(64) void k_lms_search1(V1Args A)
+__global__ __launch_bounds__(64, L == 1 ? 2 : 1) void k_lms_search1(V1Args A)
 {
     __shared__ LmsShared<L> sh;
     search1_predictor<DEPTH, T, L>(sh, A, blockIdx.x, threadIdx.x, nullptr);
@@ -753,8 +762,10 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
 }
 
 // <T3, L3>: mapping of the 4-tap rows, <T7, L7>: of the 8-tap rows (<4, 1> and <4, 2>; <2, 2> and <2, 4> for tiny batches)
-template <int DEPTH, int CH, int T3 = 4, int L3 = 1, int T7 = 4, int L7 = 2>
-__global__ __launch_bounds__(64) void k_lms_search2(V1Args A, uint32_t nb3)
+// WAVES: waves per SIMD the register budget must allow (2 in the throughput regime, where latency is hidden by the other
+// wave; 1 where a wave has its SIMD to itself and every spill would sit on its serial chain)
+template <int DEPTH, int CH, int T3 = 4, int L3 = 1, int T7 = 4, int L7 = 2, int WAVES = 1>
+__global__ __launch_bounds__(64, WAVES) void k_lms_search2(V1Args A, uint32_t nb3)
 {
     __shared__ union {
         LmsShared<L3> s1;
@@ -1237,7 +1248,7 @@ __global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits,
     g.wleft = A.wcap - 1;
     golf_stream<true, true, NoWait, LAZY>(g, n, wave_max(n), chanBits, recip, one_plane(A.resC, A.colsPad, col), NoWait(),
                                           A.idleFast != 0);
-    golf_flush<true>(g);
+    golf_flush<true, LAZY>(g);
     if (active) rec->c[c].bits = g.bits;
 }
 
@@ -1383,6 +1394,8 @@ static void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxS
             const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
             if (narrow)
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
+            else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
             else
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
             if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);

@@ -28,6 +28,9 @@ struct GolF {
     uint64_t acc;      // the most recent bits, right aligned; the low `nacc` of them are not yet a full word
     uint32_t nacc, wleft;
     uint32_t *wp;      // where the word being assembled goes
+    // LAZY form only: completed words not yet stored — the last qn of (q0, q1, q2, q3), oldest first — so that they leave
+    // four at a time in one 16-byte store (wp stays 16-byte aligned: slots are wcap words apart, wcap a multiple of 4)
+    uint32_t q0, q1, q2, q3, qn;
 };
 
 __device__ __forceinline__ void golf_reset(GolF &g)
@@ -41,6 +44,7 @@ __device__ __forceinline__ void golf_reset(GolF &g)
     g.nacc = 0;
     g.wleft = 0;
     g.wp = nullptr;
+    g.q0 = g.q1 = g.q2 = g.q3 = g.qn = 0;
 }
 
 // Append the low `nbits` (<= 32) of value.  The word under assembly is stored EVERY time (left aligned; a later
@@ -61,23 +65,45 @@ __device__ __forceinline__ void golf_put(GolF &g, uint32_t value, uint32_t nbits
         // symbol that are complete (final coder at 125 000 packets: 4.95 -> 2.18 ms).
         const uint32_t word = (uint32_t)((g.acc << ((64u - g.nacc) & 63u)) >> 32);
         if constexpr (LAZY) {
-            if (g.nacc >> 5) *g.wp = word;
+            // a put completes at most one word (nacc < 32 before, nbits <= 32): shift it into the 4-word queue, and when
+            // the queue is full send it off as ONE 16-byte store — a quarter of the scattered store instructions
+            const bool full = (g.nacc >> 5) != 0;
+            g.q0 = full ? g.q1 : g.q0;
+            g.q1 = full ? g.q2 : g.q1;
+            g.q2 = full ? g.q3 : g.q2;
+            g.q3 = full ? word : g.q3;
+            g.qn += full ? 1u : 0u;
+            if (g.qn == 4) {
+                *(uint4 *)g.wp = make_uint4(g.q0, g.q1, g.q2, g.q3);
+                const uint32_t adv = g.wleft >= 4 ? 4u : 0u;  // capacity reached: stay (the packet escapes anyway)
+                g.wleft -= adv;
+                g.wp += adv;
+                g.qn = 0;
+            }
         } else {
             *g.wp = word;
+            const uint32_t adv = min(g.nacc >> 5, g.wleft);  // capacity reached: stay (the packet escapes anyway)
+            g.wleft -= adv;
+            g.wp += adv;
         }
-        const uint32_t adv = min(g.nacc >> 5, g.wleft);  // capacity reached: stay (the packet escapes anyway)
-        g.wleft -= adv;
-        g.wp += adv;
         g.nacc &= 31u;
     }
 }
 
 // the bits left over after the last full word (golf_put stores before it advances)
-template <bool WRITE>
+template <bool WRITE, bool LAZY = false>
 __device__ __forceinline__ void golf_flush(GolF &g)
 {
     if constexpr (WRITE) {
-        if (g.nacc > 0) *g.wp = (uint32_t)((g.acc << (64u - g.nacc)) >> 32);
+        if constexpr (LAZY) {
+            // queued whole words first (the last qn of q0..q3), then the partial one behind them
+            if (g.qn == 3) g.wp[0] = g.q1;
+            if (g.qn >= 2) g.wp[g.qn - 2] = g.q2;
+            if (g.qn >= 1) g.wp[g.qn - 1] = g.q3;
+            if (g.nacc > 0) g.wp[g.qn] = (uint32_t)((g.acc << (64u - g.nacc)) >> 32);
+        } else {
+            if (g.nacc > 0) *g.wp = (uint32_t)((g.acc << (64u - g.nacc)) >> 32);
+        }
     }
 }
 
