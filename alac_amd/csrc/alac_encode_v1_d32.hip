@@ -1,0 +1,8 @@
+// alac_encode_v1_d32.hip — the 32-bit instantiations of the tap-parallel encode pipeline (one translation unit per bit
+// depth: the build compiles them side by side).
+#include "alac_encode_v1_impl.hpp"
+
+namespace alacdev {
+template void launch_v1_typed<32, 1>(const V1Args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const PackArgs &, const V1Streams &);
+template void launch_v1_typed<32, 2>(const V1Args &, uint32_t, uint32_t, hipStream_t, hipEvent_t *, const PackArgs &, const V1Streams &);
+}  // namespace alacdev

@@ -1,0 +1,1410 @@
+// alac_encode_v1_impl.hpp — the tap-parallel encode pipeline: every kernel and the per-depth launcher (included by
+// alac_encode_v1_d16/20/24/32.hip, one explicit instantiation each).
+//
+// Per "packet position" of the segments (position 0 only when every packet is its own segment):
+//   k_lms_search1   LPC+mix: the five mixRes passes over N/8 samples walking row 7 (stereo only)
+//   k_gol_count     adaptive-Golomb bit counts of those passes, one lane per (chain, pass) stream
+//   k_decide1       best mixRes per packet
+//   k_lms_search2   LPC+mix: the 8 converge passes of rows 3 and 7 (mono: 7 + 1 passes)
+//   k_gol_count     bit counts (first part from the last converge pass, tail from the mixRes = 4 pass:
+//                   the stale-predictor-tail quirk of SURVEY.md §3.2)
+//   k_decide2       numU / numV, escape estimate, header coefficients
+//   k_lms_final     LPC+mix: the final pass over N samples with the chosen row
+//   k_gol_final     adaptive-Golomb coder writing the per-channel bit strings, one lane per chain
+// then once: k_finalize (sizes + the "too big -> escape" rule), k_scan_sizes, k_pack (alac_encode.hip).
+//
+// The LPC+mix kernels are the tap-parallel form of alac_lms.hpp: one wave = 8 chains x 8 taps,
+// inputs staged in LDS tile by tile, residual tiles flushed to HBM in [sample][stream] order so that
+// the lane-per-stream Golomb kernels read them coalesced.
+//
+// Reference control flow: codec/ALACEncoder.cu:290-558 (EncodeStereo), :812-963 (EncodeMono).
+#pragma once
+#include <cstdlib>
+#include <type_traits>
+#include "alac_encode_v1_types.hpp"
+#include "alac_lms.hpp"
+#include "alac_golomb.hpp"
+
+namespace alacdev {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (indices that MUST fold, e.g. into
+// register-array subscripts, cannot be left to the unroller)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; 12 keeps
+                                  // the 16-byte PCM loads of the staging aligned)
+// Tile geometry by lanes per chain.  One lane per chain = 64 chains per wave: a 64-step tile would take 23 KB of LDS per
+// wave (6 waves per CU); 32 steps take 14.8 KB (10 per CU).  These mappings run where many waves share a SIMD (throughput
+// regime) or off the critical path (the 4-tap rows of the search), so the extra tile boundaries are cheap there.
+template <int LPC>
+struct Geo {
+    static constexpr int TILE = LPC == 1 ? 32 : 64;   // predictor steps per LDS tile
+    static constexpr int ROWLEN = kHist + TILE + 4;   // staged samples per row (80 / 48)
+    static constexpr int STRIDE = ROWLEN + 9;         // dwords per input row: + 9 cells of operand prefetch over-read /
+                                                      // warm-up parking; odd (89 / 57)
+};
+constexpr int kZeroCells = 24;    // zeros fed to lanes that hold no active tap
+
+
+__device__ __forceinline__ bool seg_packet(const SegView &S, uint32_t seg, uint32_t &p, uint32_t &N)
+{
+    p = 0;
+    N = 0;
+    if (seg >= S.segEnd) return false;
+    const uint32_t p0 = S.segFirst ? S.segFirst[seg] : seg;
+    const uint32_t p1 = S.segFirst ? S.segFirst[seg + 1] : seg + 1;
+    p = p0 + S.pos;
+    if (p >= p1) {
+        p = 0;  // a lane without a packet still forms addresses from p (idle-lane fast paths): keep it in range
+        return false;
+    }
+    N = S.numSamples ? S.numSamples[p] : S.frameSize;
+    N = N < S.frameSize ? N : S.frameSize;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// One wave per workgroup: its LDS operations execute in program order, so phases that hand data through LDS
+// only need the compiler not to reorder them (a real fence would also drain the global loads and stores that
+// are deliberately left in flight across the tile's compute).
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+// ---- producer -> consumer hand-off inside one launch (cdna_hip_programming.md Guideline 16) ----
+// The residual rows are stored with agent-scope atomic stores (global_store ... sc1: written through the
+// XCD's L2), so once `s_waitcnt vmcnt(0)` has seen them complete there is nothing left in this L2 for a
+// release to write back, and the flag can follow directly.  Measured: an agent-scope release fence here
+// (buffer_wbl2 of the WHOLE L2, which also holds the coder waves' dirty bit words) costs ~11 us per
+// publish; ALAC_HIP_PUBFENCE=1 puts it back (and publishes every 4 tiles instead of every tile).
+__device__ __forceinline__ void publish_rows(uint32_t *flag, uint32_t rows, int lane, bool fence, uint32_t lose = 0)
+{
+    if (lose) return;  // ALAC_HIP_DEBUG_LOSE_HANDOFF: the consumers must notice
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (fence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) __hip_atomic_store(flag, rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Consumer: relaxed poll of the (two) producer words, then ONE agent-scope acquire before any newly
+// published row is loaded.  The spin is bounded; a consumer that gives up has NOT seen its rows: it raises the
+// context's error word (host-mapped, checked at the next synchronize -> the call fails with kALAC_MemFullError) and
+// carries on with whatever is there, so the launch still drains.
+// Forward progress: producers are the workgroups [0, nLms) of the launch and never wait for anything, so each of them
+// finishes in bounded time once it is resident; a consumer only ever waits for producers.  The dispatcher hands out
+// workgroups in id order in practice (producers first), but nothing here DEPENDS on that: if consumers were resident
+// first they would hold at most their own SIMD slots while spinning with s_sleep, producers fill the remaining slots
+// or follow as consumers time out — the outcome is then an error, never a hang and never silent corruption.
+struct RowWait {
+    const uint32_t *f[4];  // producer progress words (a coder wave's 64 chains come from 1, 2 or 4 predictor waves)
+    uint32_t n;
+    uint32_t avail, base;
+    HandoffCtl ho;
+    // producers first .. first + count - 1, of which only those below `limit` exist
+    __device__ __forceinline__ void producers(const uint32_t *flags, uint32_t first, uint32_t count, uint32_t limit)
+    {
+        n = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            f[i] = flags + first;
+            if (i < count && first + i < limit) {
+                f[i] = flags + first + i;
+                n = i + 1;
+            }
+        }
+    }
+    __device__ __forceinline__ void operator()(uint32_t rows)
+    {
+        rows += base;
+        if (avail >= rows) return;
+        for (uint32_t spins = 0; spins < ho.spinLimit; spins++) {
+            uint32_t m = 0xffffffffu;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (i < n) m = min(m, __hip_atomic_load(f[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            avail = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+            if (avail >= rows) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (avail < rows) {
+            if (ho.err && threadIdx.x == 0) __hip_atomic_store(ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            avail = 0xffffffffu;  // stop polling: the call is already lost
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+};
+
+
+
+// ================================================================================================
+// LPC + mix kernels.  One wave = SLOTS chains (64 / LPC), see alac_lms.hpp for the lane mapping.
+// ================================================================================================
+
+// per-wave LDS
+template <int LPC>
+struct LmsShared {
+    static constexpr int SLOTS = 64 / LPC;
+    int32_t xs[(SLOTS + 2) * Geo<LPC>::STRIDE];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
+                                          // the residuals as the steps pass (+ two dump rows: inert lanes, and the u / v
+                                          // of the surplus staging tasks when TASKS is not a multiple of 64)
+    int32_t zero[kZeroCells];
+    uint32_t pktIdx[SLOTS], pktN[SLOTS];  // per input row: packet and its valid samples
+    int32_t rowMix[SLOTS];                // mixRes of the row's packet (this pass)
+};
+
+// Staging of x[j0 - kHist .. j0 + kTile + 4) of every chain of the wave, split in two so that the global
+// loads of tile t+1 are in flight while tile t computes:
+//   stage_load   16-byte PCM loads (4 sample-frames per lane task) into registers
+//   stage_store  stereo mix (codec/matrix_enc.cu:72-99 and the 20/24/32-bit forms) or mono widening, then LDS;
+//                out-of-range samples -> 0
+template <int CH, int LPC>
+struct StageRegs {
+    static constexpr int SLOTS = 64 / LPC;
+    static constexpr int TASKS = (SLOTS / CH) * (Geo<LPC>::ROWLEN / 4);  // (packet, 4-sample group) pairs
+    static constexpr int ITERS = (TASKS + 63) / 64;
+    int32_t v[ITERS][9];  // raw PCM dwords of each task: 4 sample-frames = CH * bytes-per-sample dwords (<= 8), +1 spare
+};
+
+// channel-sample s (0 .. 4 CH - 1) of a task's dwords, after the shift-off of the low bytes — what load_lr /
+// load_sample >> SH deliver (codec/matrix_enc.cu:79-82, :129-134, :197-202, :338-342); s is a compile-time
+// constant wherever this is called, so everything folds to one or two shifts
+template <int DEPTH, int S>
+__device__ __forceinline__ int32_t task_sample(const int32_t (&w)[9])
+{
+    if constexpr (DEPTH == 16) {
+        return (S & 1) ? (w[S >> 1] >> 16) : (int32_t)(int16_t)w[S >> 1];
+    } else if constexpr (DEPTH == 32) {
+        return w[S] >> 16;  // bytesShifted = 2
+    } else {
+        constexpr int o = 3 * S, i = o >> 2, shb = (o & 3) * 8;
+        const uint32_t lo = (uint32_t)w[i], hi = (uint32_t)w[i + 1];
+        // the 3 bytes at byte offset o, left aligned in a dword
+        uint32_t x;
+        if constexpr (shb == 0) x = lo << 8;
+        else if constexpr (shb == 8) x = lo & 0xffffff00u;
+        else x = ((hi << (32 - shb)) | (lo >> shb)) << 8;
+        return DEPTH == 20 ? ((int32_t)x >> 12) : ((int32_t)x >> 16);  // 20: full value; 24: >> 8 (bytesShifted = 1)
+    }
+}
+
+// vector width of a task's loads: the PCM base is 16-byte aligned, so the packet stride decides whether they apply
+template <int DEPTH, int CH>
+__device__ __forceinline__ bool task_vec_ok(uint32_t frameBytes)
+{
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+    constexpr uint32_t ALIGN = (BPF == 4 || BPF == 8) ? 16 : ((BPF & 1) == 0 ? 8 : 4);
+    return (frameBytes & (ALIGN - 1)) == 0;
+}
+
+// the BPF dwords of one task (4 sample-frames) starting at src
+template <int DEPTH, int CH>
+__device__ __forceinline__ void task_load(const uint8_t *src, int32_t (&w)[9])
+{
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);  // bytes per sample-frame = dwords per 4-frame task
+    if constexpr (BPF == 4) {  // 16-bit stereo: the task is 16 bytes, 16-byte aligned
+        const int4 w4 = *(const int4 *)src;
+        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+    } else if constexpr (BPF == 8) {  // 32-bit stereo: 32 bytes, 16-byte aligned
+        const int4 a4 = ((const int4 *)src)[0], b4 = ((const int4 *)src)[1];
+        w[0] = a4.x; w[1] = a4.y; w[2] = a4.z; w[3] = a4.w;
+        w[4] = b4.x; w[5] = b4.y; w[6] = b4.z; w[7] = b4.w;
+    } else if constexpr ((BPF & 1) == 0) {  // 8-byte aligned tasks: 16-bit mono (8 B), 20/24-bit stereo (24 B)
+#pragma unroll
+        for (int k = 0; k < BPF; k += 2) {
+            const int2 w2 = ((const int2 *)src)[k >> 1];
+            w[k] = w2.x;
+            w[k + 1] = w2.y;
+        }
+    } else {  // 20/24-bit mono: 12 bytes, dword aligned
+#pragma unroll
+        for (int k = 0; k < BPF; k++) w[k] = ((const int32_t *)src)[k];
+    }
+    w[BPF] = 0;  // task_sample's over-read of the last 3-byte sample
+}
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_load(StageRegs<CH, LPC> &R, const LmsShared<LPC> &sh, const uint8_t *pcm,
+                                           uint32_t frameBytes, int j0, int lane)
+{
+    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+    const bool vec = task_vec_ok<DEPTH, CH>(frameBytes);
+#pragma unroll
+    for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
+        const int idx = it * 64 + lane;
+        const int q = idx / GROUPS, grp = idx - q * GROUPS;
+        const int row = q * CH;
+#pragma unroll
+        for (int k = 0; k <= BPF; k++) R.v[it][k] = 0;
+        if (idx < StageRegs<CH, LPC>::TASKS && vec) {
+            const uint32_t N = sh.pktN[row];
+            const int jb = j0 - kHist + grp * 4;
+            // a group that starts inside the packet is loaded whole: its tail may lie past N but never past the
+            // packet's full-size slot in the PCM buffer
+            if (jb >= 0 && jb < (int)N)
+                task_load<DEPTH, CH>(pcm + (uint64_t)sh.pktIdx[row] * frameBytes + (uint64_t)jb * BPF, R.v[it]);
+        }
+    }
+}
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShared<LPC> &sh, const uint8_t *pcm,
+                                            uint32_t frameBytes, int j0, int lane)
+{
+    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
+    constexpr int SH = 8 * (int)bytes_shifted(DEPTH);
+    const bool vec = task_vec_ok<DEPTH, CH>(frameBytes);
+#pragma unroll
+    for (int it = 0; it < StageRegs<CH, LPC>::ITERS; it++) {
+        const int idx = it * 64 + lane;
+        if (idx >= StageRegs<CH, LPC>::TASKS) continue;
+        const int q = idx / GROUPS, grp = idx - q * GROUPS;
+        const int row = q * CH;
+        const uint32_t N = sh.pktN[row];
+        const int jb = j0 - kHist + grp * 4;
+        const int mixres = CH == 2 ? sh.rowMix[row] : 0;
+        int32_t u[4] = {0, 0, 0, 0}, v[4] = {0, 0, 0, 0};
+        if (jb >= 0 && jb < (int)N) {
+            if (vec) {
+                static_for<4>([&](auto T) {
+                    constexpr int t = decltype(T)::value;
+                    const bool in = jb + t < (int)N;
+                    if constexpr (CH == 2) {
+                        const int32_t l = task_sample<DEPTH, 2 * t>(R.v[it]), r = task_sample<DEPTH, 2 * t + 1>(R.v[it]);
+                        u[t] = in ? mix_sample(mixres, 0, l, r) : 0;
+                        v[t] = in ? mix_sample(mixres, 1, l, r) : 0;
+                    } else {
+                        u[t] = in ? task_sample<DEPTH, t>(R.v[it]) : 0;
+                    }
+                });
+            } else {
+                // packets that are not vector aligned (odd frame sizes): sample by sample
+                const uint8_t *pk = pcm + (uint64_t)sh.pktIdx[row] * frameBytes;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (jb + t < (int)N) {
+                        if constexpr (CH == 2) {
+                            int32_t l, r;
+                            load_lr<DEPTH>(pk, (uint32_t)(jb + t), l, r);
+                            u[t] = mix_sample(mixres, 0, l, r);
+                            v[t] = mix_sample(mixres, 1, l, r);
+                        } else {
+                            u[t] = load_sample<DEPTH>(pk, (uint32_t)(jb + t)) >> SH;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            sh.xs[row * Geo<LPC>::STRIDE + grp * 4 + t] = u[t];
+            if constexpr (CH == 2) sh.xs[(row + 1) * Geo<LPC>::STRIDE + grp * 4 + t] = v[t];
+        }
+    }
+}
+
+// ---- interior fast path of the staging (tile and its history fully inside every packet of the
+// wave): everything that does not change from tile to tile is computed once per pass, and a tile costs one
+// few vector loads plus the mix and the LDS writes per task — no bounds checks, no branches.
+template <int CH, int LPC>
+struct StagePlan {
+    static constexpr int ITERS = StageRegs<CH, LPC>::ITERS;
+    const uint8_t *pk[ITERS];  // address of the task's 4 sample-frames when the tile starts at j0 = kHist
+    int xs[ITERS];             // LDS cell of the task's first u (v follows one row further)
+    int32_t wl[ITERS], wr[ITERS], vsel[ITERS];  // u = (wl l + wr r) >> 2; v = vsel ? l - r : r
+    int32_t keep[ITERS];       // 0 for the tasks in front of sample 0 when the first tile is staged (HEAD), else -1
+    bool usable;               // dword-aligned packets
+};
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShared<LPC> &sh, const uint8_t *pcm,
+                                           uint32_t frameBytes, int lane)
+{
+    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);  // bytes per sample-frame = dwords per 4-frame task
+    P.usable = task_vec_ok<DEPTH, CH>(frameBytes);
+#pragma unroll
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+        const int idx = it * 64 + lane;
+        const int q = idx / GROUPS, grp = idx - q * GROUPS;
+        // 16 chains per wave make 160 tasks: the 32 surplus lanes of the third round load row 0's samples again and
+        // store into the dump rows (the fast paths carry no per-task predicate)
+        const bool real = idx < StageRegs<CH, LPC>::TASKS;
+        const int row = real ? q * CH : 0;
+        P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * BPF);
+        P.xs[it] = (real ? row : StageRegs<CH, LPC>::SLOTS) * Geo<LPC>::STRIDE + grp * 4;
+        const int32_t r = CH == 2 ? sh.rowMix[row] : 0;
+        P.wl[it] = r ? r : (1 << kMixBits);
+        P.wr[it] = r ? (1 << kMixBits) - r : 0;
+        P.vsel[it] = r ? -1 : 0;
+        P.keep[it] = grp < kHist / 4 ? 0 : -1;
+    }
+}
+
+// HEAD: the tile that starts at sample 0 — the kHist samples in front of it are zeros, their tasks load nothing
+template <int DEPTH, int CH, int LPC, bool HEAD = false>
+__device__ __forceinline__ void stage_load_fast(StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P, int j0)
+{
+    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+    const int64_t byteOff = (int64_t)(j0 - kHist) * BPF;
+#pragma unroll
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+        if constexpr (HEAD) {
+#pragma unroll
+            for (int k = 0; k <= BPF; k++) R.v[it][k] = 0;
+            if (P.keep[it]) task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
+        } else {
+            task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
+        }
+    }
+}
+
+template <int DEPTH, int CH, int LPC>
+__device__ __forceinline__ void stage_store_fast(const StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P,
+                                                 LmsShared<LPC> &sh)
+{
+#pragma unroll
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
+        static_for<4>([&](auto T) {
+            constexpr int t = decltype(T)::value;
+            if constexpr (CH == 2) {
+                const int32_t l = task_sample<DEPTH, 2 * t>(R.v[it]), r = task_sample<DEPTH, 2 * t + 1>(R.v[it]);
+                // codec/matrix_enc.cu:72-99 with the mixRes = 0 case folded into the weights (4 l >> 2 == l)
+                sh.xs[P.xs[it] + t] = (__mul24(P.wl[it], l) + __mul24(P.wr[it], r)) >> kMixBits;
+                sh.xs[P.xs[it] + Geo<LPC>::STRIDE + t] = P.vsel[it] ? l - r : r;
+            } else {
+                sh.xs[P.xs[it] + t] = task_sample<DEPTH, t>(R.v[it]);
+            }
+        });
+    }
+}
+
+// The LDS operands of a step (the sample entering the lane's history window, top, in[j]) depend on nothing
+// the recurrence produces: the operands of block i+1 (8 steps) are fetched while block i computes.
+struct StepOps {
+    int32_t nx[8], tp[8], cu[8];
+};
+
+__device__ __forceinline__ void load_ops(StepOps &o, const int32_t *pn, const int32_t *pt, const int32_t *pc)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        o.nx[s] = pn[s];
+        o.tp[s] = pt[s];
+        o.cu[s] = pc[s];
+    }
+}
+
+template <int T, int LPC, bool MASKED>
+__device__ __forceinline__ void run_block(int32_t (&a)[T], int32_t (&w)[T], const StepOps &o, const LmsLaneT<T> &L, int jb,
+                                          int32_t *resAt, uint32_t chanbits)
+{
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int j = jb + s;
+        const int32_t liveMask = MASKED ? (((j >= L.jlo) & (j < L.jhi)) ? -1 : 0) : -1;
+        resAt[s] = lms_step<T, LPC, MASKED>(a, w, o.tp[s], o.cu[s], liveMask, L, chanbits);
+#pragma unroll
+        for (int i = T - 1; i > 0; i--) w[i] = w[i - 1];
+        w[0] = o.nx[s];
+    }
+}
+
+// per-lane view of its chain inside the wave's LDS
+struct LaneView {
+    const int32_t *row;   // xs row of the chain (x[j] at row[kHist + j - j0])
+    int32_t *res;         // residual row (dump row for inert lanes)
+    const int32_t *zero;
+    bool feeds;           // this lane holds at least one active tap
+};
+
+// one tile [j0, jEnd) of steps; the history windows are (re)loaded from LDS at the tile start
+template <int T, int LPC>
+__device__ __forceinline__ void run_tile(int32_t (&a)[T], const LaneView &V, const LmsLaneT<T> &L, int j0, int jEnd,
+                                         uint32_t chanbits)
+{
+    const int adv = V.feeds ? 1 : 0;
+    // x[j] lives at row[kHist + j - j0].  nx of step j = x[j - T h] enters the window for step j + 1
+    const int32_t *pn = V.feeds ? V.row + kHist - T * L.h : V.zero;
+    const int32_t *pt = V.feeds ? V.row + kHist - 1 - L.na : V.zero;
+    const int32_t *pc = V.row + kHist;
+    int32_t w[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) w[i] = V.feeds ? V.row[kHist - 1 - T * L.h - i] : 0;
+    StepOps opA, opB;  // ping-pong: no register copies between blocks
+    load_ops(opA, pn, pt, pc);
+    auto block = [&](const StepOps &cur, StepOps &nxt, int jb) {
+        const int o = jb - j0;
+        load_ops(nxt, pn + adv * (o + 8), pt + adv * (o + 8), pc + (o + 8));
+        const bool allLive = __all((jb >= L.jlo) & (jb + 8 <= L.jhi));  // wave-uniform
+        if (allLive)
+            run_block<T, LPC, false>(a, w, cur, L, jb, V.res + o, chanbits);
+        else
+            run_block<T, LPC, true>(a, w, cur, L, jb, V.res + o, chanbits);
+    };
+    for (int jb = j0; jb < jEnd; jb += 16) {
+        block(opA, opB, jb);
+        if (jb + 8 < jEnd) block(opB, opA, jb + 8);
+        else opA = opB;
+    }
+}
+
+// what one wave does in one LPC kernel
+struct ChainJob {
+    bool active;
+    uint32_t seg, ch, p, N;   // chain identity and its packet
+    int na;                   // taps of the row it walks
+    int16_t *row;             // the persistent coefficient row (first tap)
+};
+
+// A pass = one pc_block call over every chain of the wave: `num` samples adapt the row, residual positions
+// j < P go to dst[j * streamStride + stream] when store is set.
+// ZZ: residuals leave as their zig-zag image 2|del| - (del < 0) (what the final entropy coder starts from)
+template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false, int T = 4>
+__device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[T],
+                                         uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
+                                         uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0,
+                                         StageRegs<CH, LPC> *head = nullptr, int headMode = 0)
+{
+    // head / headMode: the raw PCM of the first tile is the same for every pass a kernel makes over a packet
+    // (only the mix weights change): mode 1 keeps it in *head, mode 2 re-mixes it from there instead of loading
+    // it again — the first tile's load is the one load of a pass whose latency nothing hides.
+    constexpr int SLOTS = 64 / LPC;
+    constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
+    const uint32_t frameBytes = A.S.frameSize * CH * bytes_per_sample(DEPTH);
+    const int slot = lane / LPC;
+    LmsLaneT<T> L = make_lane<T, LPC>(lane, J.na, J.active ? (int)num : 0);
+    // Lanes without work (pad lanes, escape packets in the final pass) must not drag the wave onto the checked
+    // paths: they count as "live", as owning every row and as fully inside their packet.  What they compute and
+    // store goes to rows / slots nobody reads.
+    const uint32_t idleVal = A.idleFast ? 0xffffffffu : 0u;  // what a lane without work reports to the wave minima
+    if (!J.active && A.idleFast) {
+        L.jlo = 0;
+        L.jhi = 0x7fffffff;
+    }
+    LaneView V;
+    V.feeds = J.active && (T * L.h < J.na);
+    V.row = sh.xs + slot * Geo<LPC>::STRIDE;
+    V.res = V.feeds ? sh.xs + slot * Geo<LPC>::STRIDE : sh.xs + SLOTS * Geo<LPC>::STRIDE;
+    V.zero = sh.zero;
+    // the lane that flushes slot fs = lane % SLOTS needs that slot's P / stream / activity
+    const int fs = lane % SLOTS;
+    const uint32_t fP = (uint32_t)__shfl((int)(J.active ? P : 0), fs * LPC);
+    const uint32_t fStream = (uint32_t)__shfl((int)stream, fs * LPC);
+    const int fNa = __shfl(J.na, fs * LPC);
+    const uint32_t runTo = wave_max(J.active ? (store ? (P > num ? P : num) : num) : 0);
+    // flush: the lane's column inside a group of LPC rows, and the first row some lane does NOT own
+    const uint32_t half = (uint32_t)(lane / SLOTS);
+    const uint32_t voff = half * (uint32_t)streamStride + fStream;
+    const bool fAct = __shfl((int)J.active, fs * LPC) != 0;
+    const uint32_t fPmin = wave_min_u32(fAct ? fP : idleVal);
+    StageRegs<CH, LPC> R;
+    StagePlan<CH, LPC> SP;
+    stage_plan<DEPTH, CH, LPC>(SP, sh, A.S.pcm, frameBytes, lane);
+    // staged window [j - kHist, j - kHist + kRowLen) inside every packet of the wave -> fast staging of tile j
+    const uint32_t nMinRows = wave_min_u32(J.active ? J.N : idleVal);
+    auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + Geo<LPC>::ROWLEN) <= nMinRows; };
+    if (runTo > 0) {
+        if (SP.usable && (uint32_t)(Geo<LPC>::ROWLEN - kHist) <= nMinRows) {  // first tile inside every packet: no bounds checks
+            if (head && headMode == 2) {
+                stage_store_fast<DEPTH, CH, LPC>(*head, SP, sh);
+            } else {
+                stage_load_fast<DEPTH, CH, LPC, true>(R, SP, 0);
+                if (head && headMode == 1) *head = R;
+                stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
+            }
+        } else {
+            stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+            stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, 0, lane);
+        }
+    }
+    for (int j0 = 0; j0 < (int)runTo; j0 += Geo<LPC>::TILE) {
+        const bool more = j0 + Geo<LPC>::TILE < (int)runTo;
+        const bool fastNext = more && interior(j0 + Geo<LPC>::TILE);
+        if (fastNext) stage_load_fast<DEPTH, CH, LPC>(R, SP, j0 + Geo<LPC>::TILE);  // in flight under the tile
+        else if (more) stage_load<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + Geo<LPC>::TILE, lane);
+        lds_order();
+        // warm-up positions of pc_block (dp_enc.c:90, :108-112): pc[0] = in[0], pc[j] = sext(in[j] - in[j-1]).  They are
+        // formed from x[0 .. na] BEFORE the steps overwrite those cells with residuals and parked in the row's prefetch
+        // over-read cells (kRowLen .. kRowLen + 8, never data), then moved to cells 0 .. na once the tile has run.
+        if (store && j0 == 0) {
+            for (int pos = lane / SLOTS; pos <= fNa; pos += LPC) {
+                const int32_t *xr = sh.xs + fs * Geo<LPC>::STRIDE + kHist;
+                sh.xs[fs * Geo<LPC>::STRIDE + Geo<LPC>::ROWLEN + pos] = pos == 0 ? xr[0] : sext(xr[pos] - xr[pos - 1], 32 - chanBits);
+            }
+            lds_order();
+        }
+        const int jEnd = min(j0 + Geo<LPC>::TILE, (int)((runTo + 7) & ~7u));
+        run_tile<T, LPC>(a, V, L, j0, jEnd, chanBits);
+        lds_order();
+        if (store) {
+            if (j0 == 0) {
+                for (int pos = lane / SLOTS; pos <= fNa; pos += LPC)
+                    sh.xs[fs * Geo<LPC>::STRIDE + pos] = sh.xs[fs * Geo<LPC>::STRIDE + Geo<LPC>::ROWLEN + pos];
+                lds_order();
+            }
+            // residual tile -> HBM, [sample][stream]: consecutive lanes = consecutive streams.  WT (fused launches):
+            // agent-scope stores, written through so that publish_rows has nothing to write back.
+            auto put = [&](int32_t *q, int32_t v) {
+                if constexpr (ZZ) v = (int32_t)(((uint32_t)v << 1) ^ (uint32_t)(v >> 31));
+                if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *q = v;
+            };
+            if ((uint32_t)(j0 + Geo<LPC>::TILE) <= fPmin) {
+                // every lane owns every row of the tile: scalar row base + lane column, no predicate, no branch
+                int32_t *tileBase = dst + (uint64_t)j0 * streamStride;
+#pragma unroll
+                for (int it = 0; it < Geo<LPC>::TILE / LPC; it++)
+                    put(tileBase + (uint64_t)(it * LPC) * streamStride + voff, sh.xs[fs * Geo<LPC>::STRIDE + it * LPC + (int)half]);
+            } else {
+#pragma unroll 4
+                for (int it = 0; it < Geo<LPC>::TILE / LPC; it++) {
+                    const int jj = it * LPC + lane / SLOTS;
+                    const uint32_t j = (uint32_t)(j0 + jj);
+                    const int32_t v = sh.xs[fs * Geo<LPC>::STRIDE + jj];
+                    if (j < fP) put(dst + (uint64_t)j * streamStride + fStream, v);
+                }
+            }
+            // fused final kernel: tell the coder waves how many residual rows are complete (every 4 tiles)
+            if (flag && ((((j0 / Geo<LPC>::TILE) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + Geo<LPC>::TILE, (int)runTo), lane, (A.pubMask >> 31) != 0, A.ho.lose);
+        }
+        lds_order();
+        if (fastNext) stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
+        else if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + Geo<LPC>::TILE, lane);
+    }
+}
+
+template <int LPC>
+__device__ __forceinline__ void lms_setup(LmsShared<LPC> &sh, const ChainJob &J, int mix, int lane)
+{
+    constexpr int SLOTS = 64 / LPC;
+    if (lane < kZeroCells) sh.zero[lane] = 0;
+    if (lane % LPC == 0) {
+        const int slot = lane / LPC;
+        sh.pktIdx[slot] = J.p;
+        sh.pktN[slot] = J.active ? J.N : 0;
+        sh.rowMix[slot] = mix;
+    }
+    (void)SLOTS;
+    lds_order();
+}
+
+template <int LPC, int T = 4>
+__device__ __forceinline__ void load_row(const ChainJob &J, int32_t (&a)[T], int lane)
+{
+    const int h = lane & (LPC - 1);
+#pragma unroll
+    for (int i = 0; i < T; i++) a[i] = (J.active && T * h + i < J.na) ? (int32_t)J.row[T * h + i] : 0;
+}
+
+template <int LPC, int T = 4>
+__device__ __forceinline__ void store_row(const ChainJob &J, const int32_t (&a)[T], int lane)
+{
+    const int h = lane & (LPC - 1);
+#pragma unroll
+    for (int i = 0; i < T; i++)
+        if (J.active && T * h + i < J.na) J.row[T * h + i] = (int16_t)a[i];
+}
+
+// ---- k_lms_search1: the five mixRes passes over N/8 samples walking row 7 (codec/ALACEncoder.cu:353-379)
+// T taps per lane x L lanes per chain = 8 (alac_lms.hpp "lane mappings"): <4, 2> or <8, 1>
+template <int DEPTH, int T, int L>
+__device__ __forceinline__ void search1_predictor(LmsShared<L> &sh, const V1Args &A, uint32_t block, int lane, uint32_t *flag)
+{
+    constexpr int SLOTS = 64 / L;
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * 2 + block * SLOTS + lane / L;
+    J.seg = chain >> 1;
+    J.ch = chain & 1;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = 8;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
+    if (A.rowReady && A.S.pos > 0) {
+        // Chained batch with overlapped positions: this launch runs BESIDE the final pass of the previous packet position.
+        // A chain whose previous packet runs its final pass on the 8-tap row must wait until that pass has stored the row;
+        // one that chose 4 taps (or escaped) left the row final when its search ended, before this launch began.
+        bool wait = false;
+        if (J.active) {
+            const PacketRec *prev = A.recs + (J.p - 1);
+            wait = !prev->escape && prev->c[J.ch].num == 8;
+        }
+        bool seen = false;
+        for (uint32_t spins = 0; spins < A.ho.spinLimit; spins++) {
+            const uint32_t r = wait ? __hip_atomic_load(A.rowReady + chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+            if (__all(r >= A.S.pos)) {
+                seen = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!seen && A.ho.err && lane == 0) __hip_atomic_store(A.ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    int32_t a[T];
+    load_row<L>(J, a, lane);
+    const uint32_t n8 = J.N / 8;
+    // The raw PCM of the first tile is the same for all five passes; keeping it in registers spares each pass the one
+    // load whose latency nothing hides — worth ~50 registers where a wave has its SIMD to itself.  The 64-chain mapping of
+    // the throughput regime would pay for them with its second wave per SIMD and has other waves to hide the load behind.
+    constexpr bool keepHead = L != 1;
+    StageRegs<2, L> headRegs;
+    StageRegs<2, L> *head = keepHead ? &headRegs : nullptr;
+    for (int r = 0; r <= kMaxRes; r++) {
+        lms_setup<L>(sh, J, r, lane);
+        if (flag)
+            lms_pass<DEPTH, 2, L, true>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain,
+                                        lane, flag, (uint32_t)r << 16, head, r == 0 ? 1 : 2);
+        else
+            lms_pass<DEPTH, 2, L>(sh, A, J, a, n8, n8, true, A.resA, 5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
+                                  nullptr, 0, head, r == 0 ? 1 : 2);
+    }
+    store_row<L>(J, a, lane);
+    if (flag) publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);
+}
+
+template <int DEPTH, int T, int L>
+__global__ __launch_bounds__(64, L == 1 ? 2 : 1) void k_lms_search1(V1Args A)
+{
+    __shared__ LmsShared<L> sh;
+    search1_predictor<DEPTH, T, L>(sh, A, blockIdx.x, threadIdx.x, nullptr);
+}
+
+// ---- k_lms_search2: converge passes for numUV = 4 (row 3, one lane per chain) and 8 (row 7, two lanes per
+// chain) in one launch: the first nb3 workgroups take the 4-tap rows (codec/ALACEncoder.cu:420-431; mono :881-893)
+// RS = 0: row 3 (numUV = 4), RS = 1: row 7 (numUV = 8); T taps per lane x LPC lanes per chain
+template <int DEPTH, int CH, int RS, int T, int LPC>
+__device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane)
+{
+    constexpr int SLOTS = 64 / LPC;
+    constexpr int rs = RS;
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * CH + block * SLOTS + lane / LPC;
+    J.seg = chain / CH;
+    J.ch = chain % CH;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = rs ? 8 : 4;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + rs * 16;
+    int32_t a[T];
+    load_row<LPC>(J, a, lane);
+    const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
+    lms_setup<LPC>(sh, J, best, lane);
+    const uint32_t n8 = J.N / 8, n32 = J.N / 32;
+    StageRegs<CH, LPC> head;
+    for (int pass = 0; pass < 8; pass++) {
+        const bool last = pass == 7;
+        const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
+        uint32_t P = num > (uint32_t)(J.na + 1) ? num : (uint32_t)(J.na + 1);  // positions pc_block writes ...
+        P = P < n8 ? P : n8;                                                   // ... that dyn_comp will read
+        lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
+                                 lane, nullptr, 0, &head, pass == 0 ? 1 : 2);
+    }
+    store_row<LPC>(J, a, lane);
+}
+
+// <T3, L3>: mapping of the 4-tap rows, <T7, L7>: of the 8-tap rows (<4, 1> and <4, 2>; <2, 2> and <2, 4> for tiny batches)
+// WAVES: waves per SIMD the register budget must allow (2 in the throughput regime, where latency is hidden by the other
+// wave; 1 where a wave has its SIMD to itself and every spill would sit on its serial chain)
+template <int DEPTH, int CH, int T3 = 4, int L3 = 1, int T7 = 4, int L7 = 2, int WAVES = 1>
+__global__ __launch_bounds__(64, WAVES) void k_lms_search2(V1Args A, uint32_t nb3)
+{
+    __shared__ union {
+        LmsShared<L3> s1;
+        LmsShared<L7> s2;
+    } sh;
+    if (blockIdx.x < nb3)
+        search2_body<DEPTH, CH, 0, T3, L3>(sh.s1, A, blockIdx.x, threadIdx.x);
+    else
+        search2_body<DEPTH, CH, 1, T7, L7>(sh.s2, A, blockIdx.x - nb3, threadIdx.x);
+}
+
+// ---- k_lms_final: final pass with the chosen row (codec/ALACEncoder.cu:505-532, :941)
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(64) void k_lms_final(V1Args A)
+{
+    __shared__ LmsShared<2> sh;
+    const int lane = threadIdx.x;
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 32u + lane / 2;
+    J.seg = chain / CH;
+    J.ch = chain % CH;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = 4;
+    int best = 0;
+    uint32_t N = J.N;
+    if (J.active) {
+        const PacketRec *rec = A.recs + J.p;
+        J.na = rec->c[J.ch].num;
+        best = (int)rec->mixRes;
+        if (rec->escape) {  // escape estimate: the final pass does not run (:463); still stage zeros
+            J.active = false;
+        }
+    }
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
+    int32_t a[4];
+    load_row<2>(J, a, lane);
+    lms_setup<2>(sh, J, best, lane);
+    lms_pass<DEPTH, CH, 2, false, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane);
+    store_row<2>(J, a, lane);
+}
+
+// ================================================================================================
+// Golomb kernels: one lane per stream, residuals read coalesced from the [sample][stream] planes
+// ================================================================================================
+
+// search1 counts: stream = r * chainsPad + chain, n8 symbols each -> bits1[stream]
+template <int CH>
+__global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
+{
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, r = blockIdx.y;
+    const uint32_t t = r * A.chainsPad + chain;
+    uint32_t p, N;
+    const bool active = seg_packet(A.S, chain / CH, p, N);
+    const uint32_t n8 = active ? N / 8 : 0;
+    const int32_t *plane = A.resA + (uint64_t)r * A.chainsPad;
+    const uint64_t stride = 5ull * A.chainsPad;
+    GolF g;
+    golf_reset(g);
+    golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, one_plane(plane, stride, chain));
+    if (active) A.bits1[t] = g.bits;
+}
+
+// ---- k_search1_fused: k_lms_search1 and k_gol_count1 in one launch.  Workgroups [0, nLms) walk the five
+// mixRes passes and publish (pass << 16) + rows; the count waves of pass r follow them through plane r.
+template <int DEPTH, int T, int L>
+__global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, uint32_t cblocks, uint32_t chanBits)
+{
+    __shared__ LmsShared<L> sh;
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    if (blockIdx.x < nLms) {
+        search1_predictor<DEPTH, T, L>(sh, A, blockIdx.x, lane, A.flags + blockIdx.x);
+    } else {
+        gol_table_init(recip, lane);
+        __syncthreads();
+        const uint32_t idx = blockIdx.x - nLms, r = idx / cblocks, w = idx % cblocks;
+        const uint32_t chain = A.S.segBegin * 2 + w * 64u + lane;
+        const uint32_t t = r * A.chainsPad + chain;
+        uint32_t p, N;
+        const bool active = seg_packet(A.S, chain >> 1, p, N);
+        const uint32_t n8 = active ? N / 8 : 0;
+        const int32_t *plane = A.resA + (uint64_t)r * A.chainsPad;
+        const uint64_t stride = 5ull * A.chainsPad;
+        GolF g;
+        golf_reset(g);
+        // the 64 chains of this wave come from 64 / (64 / L) = L producer waves
+        RowWait wait;
+        wait.producers(A.flags, L * w, L, nLms);
+        wait.avail = 0;
+        wait.base = r << 16;
+        wait.ho = A.ho;
+        golf_stream<false>(g, n8, wave_max(n8), chanBits, recip, one_plane(plane, stride, chain), wait);
+        if (active) A.bits1[t] = g.bits;
+    }
+}
+
+// codec/ALACEncoder.cu:374-380: first minimum of bits1 + bits2 over mixRes 0..4
+static __global__ void k_decide1(V1Args A)
+{
+    const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p, N;
+    if (!seg_packet(A.S, seg, p, N)) return;
+    uint32_t best = 0, minb = 1u << 31;
+    for (uint32_t r = 0; r <= (uint32_t)kMaxRes; r++) {
+        const uint32_t tot = A.bits1[r * A.chainsPad + seg * 2] + A.bits1[r * A.chainsPad + seg * 2 + 1];
+        if (tot < minb) {
+            minb = tot;
+            best = r;
+        }
+    }
+    A.recs[p].mixRes = best;
+}
+
+// search2 counts: stream = rowsel * chainsPad + chain.  Stereo: positions < P2 come from the last converge
+// pass (resB), the tail from the mixRes = 4 search pass (resA) — codec/ALACEncoder.cu:433-445.
+template <int CH>
+__global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
+{
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, rs = blockIdx.y;
+    const uint32_t t = rs * A.chainsPad + chain;
+    uint32_t p, N;
+    const bool active = seg_packet(A.S, chain / CH, p, N);
+    const uint32_t n8 = active ? N / 8 : 0, n32 = N / 32, na = rs ? 8 : 4;
+    uint32_t P2 = n8;
+    if (CH == 2) {
+        P2 = n32 > na + 1 ? n32 : na + 1;
+        P2 = P2 < n8 ? P2 : n8;
+    }
+    const uint64_t strideB = 2ull * A.chainsPad, strideA = 5ull * A.chainsPad;
+    GolF g;
+    golf_reset(g);
+    // Rows below P2 come from the last converge pass (resB), the tail from the mixRes = 4 search pass (resA).  P2 is
+    // the same for every full packet, so normally the row ADDRESS is picked with scalar selects and one load is
+    // issued per row; only waves that mix packet lengths read both planes and pick per lane.
+    const int32_t *planeB = A.resB + (uint64_t)rs * A.chainsPad, *planeA = A.resA + (uint64_t)kMaxRes * A.chainsPad;
+    const uint32_t nMax = wave_max(n8);
+    const uint32_t p2lo = wave_min_u32(active ? P2 : 0xffffffffu), p2hi = wave_max(active ? P2 : 0u);
+    if (CH == 1 || p2lo >= p2hi) {
+        RowSrc rs2;
+        rs2.p0 = planeB;
+        rs2.s0 = strideB;
+        rs2.p1 = planeA;
+        rs2.s1 = strideA;
+        rs2.split = CH == 1 ? 0xffffffffu : p2hi;
+        rs2.col = chain;
+        golf_stream<false>(g, n8, nMax, chanBits, recip, rs2);
+    } else {
+        golf_stream_fn<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
+            const int32_t b = (planeB + j * strideB)[chain], a = (planeA + j * strideA)[chain];
+            return j < P2 ? b : a;
+        });
+    }
+    if (active) A.cost2[t] = g.bits * 8 + 16 * na;  // :438, :447 / :899
+}
+
+// numU / numV, escape estimate (codec/ALACEncoder.cu:438-461, mono :899-915), header coefficients
+template <int DEPTH, int CH>
+__global__ void k_decide2(V1Args A)
+{
+    const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p, N;
+    if (!seg_packet(A.S, seg, p, N)) return;
+    PacketRec *rec = A.recs + p;
+    constexpr uint32_t SHB = bytes_shifted(DEPTH);
+    const uint32_t partial = (N != A.S.frameSize);
+    uint32_t minBits = 0;
+    for (uint32_t c = 0; c < (uint32_t)CH; c++) {
+        const uint32_t chain = seg * CH + c;
+        const uint32_t c4 = A.cost2[chain], c8 = A.cost2[A.chainsPad + chain];
+        const uint32_t num = c8 < c4 ? 8 : 4;
+        minBits += c8 < c4 ? c8 : c4;
+        rec->c[c].num = (uint16_t)num;
+        rec->c[c].bits = 0;
+        const int16_t *row = A.state + (uint64_t)seg * 64 + c * 32 + (num == 8 ? 16 : 0);
+        for (uint32_t k = 0; k < 8; k++) rec->c[c].coefs[k] = k < num ? row[k] : (int16_t)0;  // :477-485
+    }
+    if (CH == 1) {
+        rec->c[1].num = 0;
+        rec->c[1].bits = 0;
+        rec->mixRes = 0;
+    }
+    minBits += (CH == 2 ? 64 : 32) + (partial ? 32 : 0) + N * (SHB * 8) * CH;
+    const uint32_t escapeBits = N * DEPTH * CH + (partial ? 32 : 0) + 16;
+    rec->numSamples = N;
+    rec->escape = minBits >= escapeBits ? 1u : 0u;
+}
+
+// final entropy coding, one lane per chain (codec/ALACEncoder.cu:515-531, :944-945)
+template <int CH>
+__global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
+{
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x;
+    uint32_t p, N;
+    bool active = seg_packet(A.S, chain / CH, p, N);
+    const bool have = active;  // the lane's packet exists (its bit-word slot may be scribbled on even if it escapes)
+    PacketRec *rec = A.recs + p;
+    if (active && rec->escape) active = false;
+    const uint32_t c = chain % CH;
+    const uint32_t n = active ? N : 0;
+    const int32_t *plane = A.resC;
+    const uint64_t stride = A.chainsPad;
+    GolF g;
+    golf_reset(g);
+    g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
+    g.wleft = A.wcap - 1;
+    golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), NoWait(), A.idleFast != 0);
+    golf_flush<true>(g);
+    if (active) rec->c[c].bits = g.bits;
+}
+
+// ---- k_final_fused: the final predictor pass and the final entropy coder in ONE launch.  Workgroups
+// [0, nLms) are predictor waves (32 chains each), the rest are coder waves (64 chains each) that follow their
+// two producers through the residual plane, 256 samples behind.  Both kinds are single-wave workgroups and
+// together (625 + 313 at 10k packets) still fit one per SIMD, so the ~1.0 ms and ~1.3 ms of the two stages
+// overlap instead of adding up.
+template <int DEPTH, int CH, int T = 4, int L = 2>
+__global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits)
+{
+    __shared__ LmsShared<L> sh;
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    if (blockIdx.x < nLms) {
+        ChainJob J;
+        const uint32_t chain = A.S.segBegin * CH + blockIdx.x * (64u / L) + lane / L;
+        J.seg = chain / CH;
+        J.ch = chain % CH;
+        J.active = seg_packet(A.S, J.seg, J.p, J.N);
+        J.na = 4;
+        int best = 0;
+        const uint32_t N = J.N;
+        if (J.active) {
+            const PacketRec *rec = A.recs + J.p;
+            J.na = rec->c[J.ch].num;
+            best = (int)rec->mixRes;
+            if (rec->escape) J.active = false;
+        }
+        J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
+        int32_t a[T];
+        load_row<L>(J, a, lane);
+        lms_setup<L>(sh, J, best, lane);
+        uint32_t *flag = A.flagsF + blockIdx.x;
+        lms_pass<DEPTH, CH, L, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
+        store_row<L>(J, a, lane);
+        if (A.rowReady) {
+            // the next position's search may be waiting for this row (see search1_predictor)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (J.active && J.na == 8 && lane % L == 0 && !A.ho.lose)
+                __hip_atomic_store(A.rowReady + chain, A.S.pos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come (also covers inactive waves)
+    } else {
+        gol_table_init(recip, lane);
+        __syncthreads();
+        const uint32_t w = blockIdx.x - nLms;
+        const uint32_t chain = A.S.segBegin * CH + w * 64u + lane;
+        uint32_t p, N;
+        bool active = seg_packet(A.S, chain / CH, p, N);
+        const bool have = active;
+        PacketRec *rec = A.recs + p;
+        if (active && rec->escape) active = false;
+        const uint32_t c = chain % CH;
+        const uint32_t n = active ? N : 0;
+        const int32_t *plane = A.resC;
+        const uint64_t stride = A.chainsPad;
+        GolF g;
+        golf_reset(g);
+        g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
+        g.wleft = A.wcap - 1;
+        RowWait wait;
+        wait.producers(A.flagsF, L * w, L, nLms);
+        wait.avail = 0;
+        wait.base = 0;
+        wait.ho = A.ho;
+        golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
+        golf_flush<true>(g);
+        if (active) rec->c[c].bits = g.bits;
+    }
+}
+
+// ================================================================================================
+// Final pass by packet class.  After k_decide2 a packet is (a) escaped — nothing left to predict or code, (b) all
+// channels on 4 taps, (c) at least one channel on 8 taps.  The v1 final launch ran every chain of the batch on the
+// 2-lanes-x-4-taps mapping; here the chains are compacted per class so that each class gets the lane mapping that fits
+// it (alac_lms.hpp "lane mappings") and escaped packets cost nothing:
+//   throughput regime   8-tap class <8, 1>, 4-tap class <4, 1>: 64 chains per wave, fewest instructions per chain step
+//   latency regime      8-tap class <4, 2> / <2, 4>, 4-tap class <4, 1> / <2, 2>: fewer instructions per wave step
+// ================================================================================================
+
+// class of packet i of this position: 0 = nothing to do (no packet here, or escaped), else 4 or 8
+template <int CH>
+__device__ __forceinline__ uint32_t packet_class(const V1Args &A, uint32_t i, uint32_t nseg)
+{
+    if (i >= nseg) return 0;
+    uint32_t p, N;
+    if (!seg_packet(A.S, A.S.segBegin + i, p, N)) return 0;
+    const PacketRec *rec = A.recs + p;
+    if (rec->escape) return 0;
+    uint32_t widest = rec->c[0].num;
+    if (CH == 2 && rec->c[1].num > widest) widest = rec->c[1].num;
+    return widest == 8 ? 8u : 4u;
+}
+
+// Deterministic compaction in packet order, two launches of 1024-packet workgroups:
+//   k_class_count   per workgroup: packets of each class -> blockCnt[b] = {count8, count4}
+//   k_class_assign  per workgroup: its base = sum of the counts before it (every workgroup adds them up itself: a few
+//                   hundred words), columns by ballot rank; the last workgroup writes ClassInfo and the pad columns
+template <int CH>
+__global__ __launch_bounds__(1024) void k_class_count(V1Args A, uint32_t *blockCnt)
+{
+    __shared__ uint32_t wcnt[2][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+    const uint32_t c = packet_class<CH>(A, blockIdx.x * 1024u + tid, nseg);
+    const uint64_t m8 = __ballot(c == 8), m4 = __ballot(c == 4);
+    if (lane == 0) {
+        wcnt[0][wv] = (uint32_t)__popcll(m8);
+        wcnt[1][wv] = (uint32_t)__popcll(m4);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < 16; q++) t += wcnt[tid][q];
+        blockCnt[blockIdx.x * 2 + tid] = t;
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void k_class_assign(V1Args A, const uint32_t *blockCnt)
+{
+    __shared__ uint32_t wcnt[2][16];
+    __shared__ uint32_t part[4][16];  // before-me / total, per class, per wave
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+    const uint32_t nblk = gridDim.x, b = blockIdx.x;
+    // sums of the per-workgroup counts: before this workgroup, and in all
+    uint32_t before8 = 0, before4 = 0, all8 = 0, all4 = 0;
+    for (uint32_t q = tid; q < nblk; q += 1024) {
+        const uint32_t a8 = blockCnt[2 * q], a4 = blockCnt[2 * q + 1];
+        all8 += a8;
+        all4 += a4;
+        if (q < b) {
+            before8 += a8;
+            before4 += a4;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        before8 += (uint32_t)__shfl_xor((int)before8, d);
+        before4 += (uint32_t)__shfl_xor((int)before4, d);
+        all8 += (uint32_t)__shfl_xor((int)all8, d);
+        all4 += (uint32_t)__shfl_xor((int)all4, d);
+    }
+    if (lane == 0) {
+        part[0][wv] = before8;
+        part[1][wv] = before4;
+        part[2][wv] = all8;
+        part[3][wv] = all4;
+    }
+    const uint32_t c = packet_class<CH>(A, b * 1024u + tid, nseg);
+    const uint64_t m8 = __ballot(c == 8), m4 = __ballot(c == 4);
+    if (lane == 0) {
+        wcnt[0][wv] = (uint32_t)__popcll(m8);
+        wcnt[1][wv] = (uint32_t)__popcll(m4);
+    }
+    __syncthreads();
+    uint32_t s[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < 16; q++) {
+        s[0] += part[0][q];
+        s[1] += part[1][q];
+        s[2] += part[2][q];
+        s[3] += part[3][q];
+    }
+    const uint32_t n8 = s[2] * CH, n4 = s[3] * CH, base4 = (n8 + 63) & ~63u, nCols = (base4 + n4 + 63) & ~63u;
+    if (c) {
+        const uint32_t k = c == 8 ? 0 : 1;
+        uint32_t r = s[k] + (uint32_t)__popcll((k ? m4 : m8) & ((1ull << lane) - 1));
+        for (uint32_t q = 0; q < wv; q++) r += wcnt[k][q];
+        const uint32_t col = (k ? base4 : 0u) + r * CH;
+        const uint32_t chain = (A.S.segBegin + b * 1024u + tid) * CH;
+        A.colChain[col] = chain;
+        if (CH == 2) A.colChain[col + 1] = chain + 1;
+    }
+    if (b + 1 == nblk) {
+        for (uint32_t q = n8 + tid; q < base4; q += 1024) A.colChain[q] = kNoChain;
+        for (uint32_t q = base4 + n4 + tid; q < nCols; q += 1024) A.colChain[q] = kNoChain;
+        if (tid == 0) {
+            A.cls->n8 = n8;
+            A.cls->n4 = n4;
+            A.cls->base4 = base4;
+            A.cls->nCols = nCols;
+        }
+    }
+}
+
+// the chain of a column -> what lms_pass needs
+template <int CH>
+__device__ __forceinline__ void class_job(const V1Args &A, uint32_t col, uint32_t limit, ChainJob &J, int &best)
+{
+    const uint32_t chain = col < limit ? A.colChain[col] : kNoChain;
+    J.active = chain != kNoChain;
+    J.seg = J.active ? chain / CH : A.S.segBegin;
+    J.ch = J.active ? chain % CH : 0;
+    J.na = 4;
+    best = 0;
+    uint32_t p = 0, N = 0;
+    const bool have = seg_packet(A.S, J.seg, p, N);
+    J.p = p;
+    J.N = N;
+    if (J.active && have) {
+        const PacketRec *rec = A.recs + p;
+        J.na = rec->c[J.ch].num;
+        best = (int)rec->mixRes;
+    } else {
+        J.active = false;
+        J.N = 0;
+    }
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
+}
+
+// The class kernels run as separate launches (throughput regime: every kernel fills the machine on its own, plain
+// coalesced stores, no polling).  A fused producer/consumer form of this pass was measured in the latency regime
+// (10 000 packets) and lost to k_final_fused, 0.97 vs 0.77 ms: a third hot loop body in one launch does not fit the
+// instruction cache the workgroups of a CU share.
+//
+// region 0 = the 8-tap class (columns [0, base4)), region 1 = the 4-tap class (columns [base4, nCols)); the grid is
+// sized for the worst case on the host (the class counts live on the device), surplus workgroups leave at once
+template <int DEPTH, int CH, int T, int L>
+__global__ __launch_bounds__(64, 2) void k_class_pred(V1Args A, uint32_t region)
+{
+    __shared__ LmsShared<L> sh;
+    const int lane = threadIdx.x;
+    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
+    constexpr uint32_t C = 64 / L;  // columns per predictor wave
+    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * C;
+    if (col0 >= (region ? nCols : base4)) return;
+    ChainJob J;
+    int best;
+    const uint32_t col = col0 + (uint32_t)(lane / L);
+    class_job<CH>(A, col, region ? base4 + n4 : n8, J, best);
+    const uint32_t N = J.N;
+    int32_t a[T];
+    load_row<L>(J, a, lane);
+    lms_setup<L>(sh, J, best, lane);
+    lms_pass<DEPTH, CH, L, false, true>(sh, A, J, a, N, N, true, A.resC, A.colsPad, col, lane);
+    store_row<L>(J, a, lane);
+}
+
+// final entropy coding of the compacted columns, one lane per chain; LAZY: see golf_put
+template <int CH, bool LAZY>
+__global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits, uint32_t region)
+{
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
+    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * 64u;
+    if (col0 >= (region ? nCols : base4)) return;
+    gol_table_init(recip, lane);
+    __syncthreads();
+    const uint32_t col = col0 + lane;
+    const uint32_t chain = col < (col0 < base4 ? n8 : base4 + n4) ? A.colChain[col] : kNoChain;
+    uint32_t p = 0, N = 0;
+    const bool active = chain != kNoChain && seg_packet(A.S, chain / CH, p, N);
+    PacketRec *rec = A.recs + p;
+    const uint32_t c = active ? chain % CH : 0;
+    const uint32_t n = active ? N : 0;
+    GolF g;
+    golf_reset(g);
+    g.wp = A.bitWords + (active ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + (lane & 1)) * A.wcap;
+    g.wleft = A.wcap - 1;
+    golf_stream<true, true, NoWait, LAZY>(g, n, wave_max(n), chanBits, recip, one_plane(A.resC, A.colsPad, col), NoWait(),
+                                          A.idleFast != 0);
+    golf_flush<true, LAZY>(g);
+    if (active) rec->c[c].bits = g.bits;
+}
+
+// packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)
+template <int DEPTH, int CH>
+__global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numPackets, uint32_t frameSize)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numPackets) return;
+    PacketRec *rec = recs + p;
+    constexpr uint32_t SHB = bytes_shifted(DEPTH);
+    const uint32_t N = rec->numSamples;
+    const uint32_t partial = (N != frameSize);
+    const uint32_t escapeBits = N * DEPTH * CH + (partial ? 32 : 0) + 16;
+    uint32_t body = 0;
+    bool esc = rec->escape != 0;
+    if (!esc) {
+        body = 12 + 4 + (partial ? 32 : 0) + 16 + N * (SHB * 8) * CH;
+        for (uint32_t c = 0; c < (uint32_t)CH; c++) body += 16 + 16 * rec->c[c].num + rec->c[c].bits;
+        if (body >= escapeBits) esc = true;
+    }
+    if (esc) body = 12 + 4 + (partial ? 32 : 0) + N * DEPTH * CH;
+    rec->escape = esc ? 1u : 0u;
+    rec->totalBits = 7 + body + 3;
+    packetBytes[p] = (7 + body + 3 + 7) / 8;
+}
+
+
+// ================================================================================================
+// launcher
+// ================================================================================================
+template <int DEPTH, int CH>
+void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st, hipEvent_t *ev,
+                     const PackArgs &pa, const V1Streams &vs)
+{
+    constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
+    const uint32_t nsegAll = A0.S.numSegments;
+    // Sub-batches: the predictor kernels saturate VALU issue while the Golomb kernels are bound by the
+    // latency of one serial chain per lane and leave most SIMDs idle, so sub-batch h+1 starts its predictor
+    // kernels as soon as sub-batch h has finished its first one and the two kinds of kernel overlap.
+    const uint32_t H = v1_sub_batches(nsegAll, vs.numSub, CH);
+    uint32_t per = ((nsegAll + H - 1) / H + 63) & ~63u;         // whole waves per sub-batch
+    if (H > 1) (void)hipEventRecord(vs.fork, st);
+    for (uint32_t h = 0; h < H; h++) {
+        V1Args A = A0;
+        A.S.segBegin = h * per;
+        A.S.segEnd = (h + 1) * per < nsegAll ? (h + 1) * per : nsegAll;
+        if (A.S.segBegin >= A.S.segEnd) break;
+        // class layout of the final pass: every sub-batch compacts into its own window of columns
+        A.cls = A0.cls + h;
+        A.colChain = A0.colChain + (uint64_t)h * (per * CH + 128);
+        A.resC = A0.resC + (uint64_t)h * (per * CH + 128);
+        uint32_t *blockCnt = (uint32_t *)(A0.cls + kMaxSubBatches) + 2 * (A.S.segBegin / 1024 + h);
+        const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+        const uint32_t cblocks = (nseg * CH + 63) / 64;
+        hipStream_t sh = h == 0 ? st : vs.side[h - 1];
+        if (h > 0) {
+            (void)hipStreamWaitEvent(sh, vs.fork, 0);
+            (void)hipStreamWaitEvent(sh, vs.stagger[h - 1], 0);  // first predictor kernel of sub-batch h-1 done
+        }
+        // stage events: sub-batch h records into ev + h * (kNumStages + 1) on its own stream
+        hipEvent_t *evh = ev ? ev + (size_t)h * (kNumStages + 1) : nullptr;
+        // Chained tiny batches (a file = one chain of packets): packet position p + 1's mixRes search only needs the 8-tap
+        // rows, which position p leaves alone once its own search is over unless it runs its FINAL pass on them — so the
+        // positions alternate between two streams, the search launch of p + 1 starts when decide2 of p has run and its
+        // predictor waves wait, per chain, for rows that p's final pass still owns (rowReady).  The rest of p + 1 waits for
+        // p's final pass.  58-75 % of packets choose 4 taps on both channels: their successor's search (a third of a
+        // position's serial chain) disappears behind the final pass.
+        static const bool ovEnv = [] { const char *v = getenv("ALAC_HIP_OVERLAP_POS"); return !(v && v[0] == '0'); }();
+        const bool overlap = ovEnv && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
+                             A.S.frameSize / 8 < 65536u && [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
+        if (overlap) {
+            A.rowReady = A0.ovRowReady;
+            A.flagsF = A0.ovFlagsF;
+            (void)hipMemsetAsync(A.rowReady, 0, (size_t)A0.chainsPad * 4, sh);
+        }
+        for (uint32_t pos = 0; pos < maxSegPackets; pos++) {
+            A.S.pos = pos;
+            hipStream_t sp = (overlap && (pos & 1)) ? vs.side[0] : sh;
+            if (overlap && pos > 0) (void)hipStreamWaitEvent(sp, vs.stagger[(pos - 1) & 1], 0);  // decide2 of pos - 1
+            hipEvent_t *e = (evh && pos + 1 == maxSegPackets) ? evh : nullptr;
+            const bool firstPos = pos == 0;
+            if (e) (void)hipEventRecord(e[kStageLms1], sp);
+            static const bool fused = [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
+            // Two regimes (A.thru, set by launch_encode_v1 from the batch size):
+            //  latency     at most ~one predictor wave per SIMD: a stage is as slow as its longest serial chain, so the
+            //              predictor and the coder that trails it share ONE launch (producer/consumer through HBM) and a
+            //              chain gets two lanes;
+            //  throughput  many waves per SIMD: every kernel fills the machine by itself, so the stages run as separate
+            //              launches with plain coalesced stores (the 4-byte write-through hand-off stores of the fused
+            //              launches are one fabric write each and cap them at ~1 TB/s), a chain's taps sit in one lane
+            //              (fewest instructions per chain step), the final pass runs per packet class and the coder
+            //              stores only completed words.  125 000 packets: 15.8 -> ~11 ms.
+            const bool thru = A.thru != 0;
+            const bool fuse = fused && H == 1 && !thru;  // flag words are indexed by workgroup: one sub-batch only
+            const uint32_t nLms = (nseg * CH + 31) / 32;
+            // Tiny batches (a single chained file, a few hundred files side by side): the chains do not even fill one
+            // wave per SIMD at 16 chains per wave, so a chain gets FOUR lanes x 2 taps (two lanes for the 4-tap rows of the
+            // search) — ~44 instead of ~62 instructions per wave step on every serial chain of the packet position.
+            const bool narrow = A.narrow != 0 && fuse;
+            const uint32_t nLms16 = (nseg * CH + 15) / 16;
+            if constexpr (CH == 2) {
+                const bool wide = A.wide81 != 0;
+                const uint32_t nLms1 = wide ? cblocks : nLms;
+                // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
+                if (fuse && narrow && A.S.frameSize / 8 < 65536u) {
+                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
+                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 2, 4>), dim3(nLms16 + 5 * cblocks), dim3(64), 0, sp, A, nLms16, cblocks,
+                                       chanBits);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
+                } else if (fuse && A.S.frameSize / 8 < 65536u) {
+                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
+                    if (wide)
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
+                                           cblocks, chanBits);
+                    else
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
+                                           cblocks, chanBits);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
+                } else {
+                    if (wide)
+                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 8, 1>), dim3(nLms1), dim3(64), 0, sp, A);
+                    else
+                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 4, 2>), dim3(nLms1), dim3(64), 0, sp, A);
+                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
+                    hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sp, A, chanBits);
+                }
+                hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
+            } else if (e) {
+                (void)hipEventRecord(e[kStageGol1], sp);
+            }
+            if (overlap && pos > 0) (void)hipStreamWaitEvent(sp, vs.join[(pos - 1) & 1], 0);  // final pass of pos - 1
+            if (e) (void)hipEventRecord(e[kStageLms2], sp);
+            const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
+            if (narrow)
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
+            else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
+            else
+                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
+            if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+            if (e) (void)hipEventRecord(e[kStageGol2], sp);
+            hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+            hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
+            if (overlap) (void)hipEventRecord(vs.stagger[pos & 1], sp);
+            if (e) (void)hipEventRecord(e[kStageLms3], sp);
+            if (thru) {
+                // final pass by packet class: compact the packets that still need it (k_class_count, k_class_assign), then per class the
+                // lane mapping that fits it — escaped packets cost nothing, all-4-tap packets run 64 chains per wave
+                const uint32_t cwaves = (((nseg * CH + 63) & ~63u) + 64) / 64;  // worst case per region, + the padding
+                hipLaunchKernelGGL(k_class_count<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sp, A, blockCnt);
+                hipLaunchKernelGGL(k_class_assign<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sp, A, blockCnt);
+                // the two classes are independent from here on: predictor -> coder of the 4-tap class on a side stream beside
+                // those of the 8-tap class.  Each kernel alone leaves the machine unevenly filled (a few thousand waves of
+                // ~1 ms each on 1024 SIMDs, LDS-limited to 6 predictor waves per CU); side by side the light coder waves
+                // of one class fill what the predictor waves of the other cannot use.
+                // (with overlapped sub-batches the other sub-batch plays that part and the side streams are theirs)
+                const bool two = H == 1;
+                hipStream_t s2 = two ? vs.side[0] : sh;
+                if (two) {
+                    (void)hipEventRecord(vs.fork, sp);
+                    (void)hipStreamWaitEvent(s2, vs.fork, 0);
+                }
+                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sp, A, 0u);
+                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
+                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                if (two) {
+                    (void)hipEventRecord(vs.join[0], s2);
+                    (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                }
+            } else if (narrow) {
+                (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sp, A, nLms16, chanBits);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+            } else if (fuse) {
+                (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sp, A, nLms, chanBits);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+            } else {
+                hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sp, A);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+                hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sp, A, chanBits);
+            }
+            if (overlap) {
+                (void)hipEventRecord(vs.join[pos & 1], sp);
+                if (pos + 1 == maxSegPackets && sp != sh) (void)hipStreamWaitEvent(sh, vs.join[pos & 1], 0);
+            }
+            if (e) (void)hipEventRecord(e[kStageScan], sh);  // end marker of this sub-batch's last stage
+        }
+        if (h > 0) {
+            (void)hipEventRecord(vs.join[h - 1], sh);
+            (void)hipStreamWaitEvent(st, vs.join[h - 1], 0);
+        }
+    }
+    // sizes, scan, pack: once, on the caller's stream; events live in the slot after the last sub-batch
+    hipEvent_t *evt = ev ? ev + (size_t)vs.maxSub * (kNumStages + 1) : nullptr;
+    if (evt) (void)hipEventRecord(evt[kStageScan], st);
+    hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A0.recs, A0.packetBytes,
+                       numPackets, A0.S.frameSize);
+    launch_scan_pack(DEPTH, CH, A0.packetBytes, pa, numPackets, st, evt, false);
+}
+
+}  // namespace alacdev
