@@ -568,6 +568,53 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
             for (uint32_t w = sp.w0 + threadIdx.x; w < sp.w1; w += blockDim.x) one(w);
         }
     };
+    // Two spans at once (the U and the V bit string of a stereo packet): the loads of BOTH are issued before either is
+    // stored, so the packet pays one memory round trip for its bulk instead of two — the packer is bound by the chain of
+    // dependent round trips per workgroup (record -> spans -> seams), not by bandwidth.
+    auto copy_two = [&](const Span &sa, int64_t offA, auto &&srcA, const Span &sb, int64_t offB, auto &&srcB) {
+        const uint32_t shA = (uint32_t)((int64_t)sa.w0 * 32 - (offA + (int64_t)mis * 8));
+        const uint32_t shB = (uint32_t)((int64_t)sb.w0 * 32 - (offB + (int64_t)mis * 8));
+        auto oneOf = [&](const Span &sp, uint32_t sh, auto &&src, uint32_t w) {
+            const uint32_t i = w - sp.w0;
+            const uint32_t a = src(i);
+            const uint32_t b = sh ? src(i + 1) : 0u;
+            *(uint32_t *)(outAligned + (uint64_t)w * 4) = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a, b, 32 - sh) : a);
+        };
+        const uint32_t ga0 = min((sa.w0 + 3) & ~3u, sa.w1), ga1 = max(sa.w1 & ~3u, ga0);
+        const uint32_t gb0 = min((sb.w0 + 3) & ~3u, sb.w1), gb1 = max(sb.w1 & ~3u, gb0);
+        const uint32_t na = (ga1 - ga0) / 4, nb2 = (gb1 - gb0) / 4;
+        for (uint32_t g = threadIdx.x; g < max(na, nb2); g += blockDim.x) {
+            const bool ha = g < na, hb = g < nb2;
+            const uint32_t wa = ga0 + 4 * g, wb = gb0 + 4 * g;
+            const uint32_t ia = wa - sa.w0, ib = wb - sb.w0;
+            uint32_t a[5], b[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) a[q] = (ha && (q < 4 || shA)) ? srcA(ia + q) : 0u;
+#pragma unroll
+            for (int q = 0; q < 5; q++) b[q] = (hb && (q < 4 || shB)) ? srcB(ib + q) : 0u;
+            if (ha) {
+                uint4 v;
+                v.x = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[0], a[1], 32 - shA) : a[0]);
+                v.y = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[1], a[2], 32 - shA) : a[1]);
+                v.z = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[2], a[3], 32 - shA) : a[2]);
+                v.w = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[3], a[4], 32 - shA) : a[3]);
+                *(uint4 *)(outAligned + (uint64_t)wa * 4) = v;
+            }
+            if (hb) {
+                uint4 v;
+                v.x = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[0], b[1], 32 - shB) : b[0]);
+                v.y = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[1], b[2], 32 - shB) : b[1]);
+                v.z = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[2], b[3], 32 - shB) : b[2]);
+                v.w = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[3], b[4], 32 - shB) : b[3]);
+                *(uint4 *)(outAligned + (uint64_t)wb * 4) = v;
+            }
+        }
+        // the few words in front of / behind the 16-byte groups
+        for (uint32_t w = sa.w0 + threadIdx.x; w < ga0; w += blockDim.x) oneOf(sa, shA, srcA, w);
+        for (uint32_t w = ga1 + threadIdx.x; w < sa.w1; w += blockDim.x) oneOf(sa, shA, srcA, w);
+        for (uint32_t w = sb.w0 + threadIdx.x; w < gb0; w += blockDim.x) oneOf(sb, shB, srcB, w);
+        for (uint32_t w = gb1 + threadIdx.x; w < sb.w1; w += blockDim.x) oneOf(sb, shB, srcB, w);
+    };
     Span spU = {0, 0}, spV = {0, 0}, spR = {0, 0}, spS = {0, 0};
     if (!rec.escape) {
         if constexpr (SHB != 0 && (DEPTH == 24 || DEPTH == 32)) {
@@ -596,10 +643,11 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
             });
         }
         spU = span_of(offU, lenU);
-        copy_span(spU, offU, [&](uint32_t i) { return wU[i]; });
         if constexpr (CH == 2) {
             spV = span_of(offV, lenV);
-            copy_span(spV, offV, [&](uint32_t i) { return wV[i]; });
+            copy_two(spU, offU, [&](uint32_t i) { return wU[i]; }, spV, offV, [&](uint32_t i) { return wV[i]; });
+        } else {
+            copy_span(spU, offU, [&](uint32_t i) { return wU[i]; });
         }
     } else if constexpr (DEPTH == 16) {
         // raw 16-bit samples, MSB first: two little-endian samples per PCM word, swapped into place by a rotate
