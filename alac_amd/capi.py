@@ -118,7 +118,13 @@ class AlacError(RuntimeError):
 
 
 class Context:
-    """One alac_hip_ctx bound to a device and to torch's current stream on it."""
+    """One alac_hip_ctx bound to a device, enqueuing on a torch stream of its own (`self.stream`).
+
+    Stream discipline: the library's kernels run on `self.stream`; every call below first makes that stream wait for the
+    caller's current torch stream (inputs produced there — fills, copies — are complete) and afterwards makes the caller's
+    stream wait for it (events the caller records on its stream, e.g. bench.py's hand-over to the RCCL side stream, are
+    ordered behind the call), and tensors allocated inside a call are allocated and filled on `self.stream`.  Without this
+    the library would sit on a private non-blocking stream that nothing the caller does is ordered against."""
 
     def __init__(self, device=0):
         import torch
@@ -128,7 +134,7 @@ class Context:
         self.lib = load_library()
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.current_stream(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
         h = _vp()
         rc = self.lib.alac_hip_create(C.byref(h), device, _vp(self.stream.cuda_stream))
         if rc != 0:
@@ -147,6 +153,23 @@ class Context:
         except Exception:
             pass
 
+    def _call(self):
+        """context manager around one library call: see the class docstring"""
+        import contextlib
+        t = self.torch
+
+        @contextlib.contextmanager
+        def cm():
+            cur = t.cuda.current_stream(self.device)
+            if cur == self.stream:  # the caller already works on the context's stream (bench.py's timed loop): nothing to order
+                yield cur
+                return
+            self.stream.wait_stream(cur)
+            with t.cuda.stream(self.stream):
+                yield cur
+            cur.wait_stream(self.stream)
+        return cm()
+
     def _check(self, rc):
         if rc != 0:
             raise AlacError(rc, self.lib.alac_hip_last_error(self.h).decode())
@@ -163,12 +186,14 @@ class Context:
     def synth_pcm(self, first_frame, num_frames, fmt, out=None):
         """The synthetic PCM of frames [first_frame, first_frame + num_frames) generated ON THE DEVICE (same bytes as
         synth_pcm(): one generator source) -> uint8 cuda tensor."""
-        t = self.torch
-        if out is None:
-            out = t.empty(num_frames * fmt.packet_bytes, dtype=t.uint8, device=self.device)
-        assert out.numel() >= num_frames * fmt.packet_bytes
-        self._check(self.lib.alac_hip_synth_pcm(self.h, first_frame, num_frames, C.byref(fmt), out.data_ptr()))
-        return out
+        with self._call() as cur:
+            t = self.torch
+            if out is None:
+                out = t.empty(num_frames * fmt.packet_bytes, dtype=t.uint8, device=self.device)
+            assert out.numel() >= num_frames * fmt.packet_bytes
+            self._check(self.lib.alac_hip_synth_pcm(self.h, first_frame, num_frames, C.byref(fmt), out.data_ptr()))
+            out.record_stream(cur)
+            return out
 
     # ---- encode ----------------------------------------------------------------------------
     def encode_buffers(self, fmt, num_packets):
@@ -183,21 +208,25 @@ class Context:
                bufs=None):
         """pcm: uint8 cuda tensor (num_packets * fmt.packet_bytes).  Returns the buffers dict
         (out, sizes, offsets); offsets[-1] is the total byte count.  Asynchronous."""
-        t = self.torch
-        assert pcm.is_cuda and pcm.dtype == t.uint8 and pcm.numel() >= num_packets * fmt.packet_bytes
-        nseg = num_packets if seg_first is None else seg_first.numel() - 1
-        bufs = bufs or self.encode_buffers(fmt, num_packets)
-        wsb = int(self.lib.alac_hip_encode_workspace_bytes(C.byref(fmt), num_packets, nseg))
-        ws = self._workspace(wsb)
-        rc = self.lib.alac_hip_encode(
-            self.h, C.byref(fmt), pcm.data_ptr(),
-            None if num_samples is None else num_samples.data_ptr(), num_packets,
-            None if seg_first is None else seg_first.data_ptr(), nseg,
-            None if state is None else state.data_ptr(), 1 if state_in else 0,
-            ws.data_ptr(), ws.numel(), bufs["out"].data_ptr(), bufs["out"].numel(),
-            bufs["sizes"].data_ptr(), bufs["offsets"].data_ptr())
-        self._check(rc)
-        return bufs
+        with self._call() as cur:
+            t = self.torch
+            assert pcm.is_cuda and pcm.dtype == t.uint8 and pcm.numel() >= num_packets * fmt.packet_bytes
+            nseg = num_packets if seg_first is None else seg_first.numel() - 1
+            bufs = bufs or self.encode_buffers(fmt, num_packets)
+            wsb = int(self.lib.alac_hip_encode_workspace_bytes(C.byref(fmt), num_packets, nseg))
+            ws = self._workspace(wsb)
+            rc = self.lib.alac_hip_encode(
+                self.h, C.byref(fmt), pcm.data_ptr(),
+                None if num_samples is None else num_samples.data_ptr(), num_packets,
+                None if seg_first is None else seg_first.data_ptr(), nseg,
+                None if state is None else state.data_ptr(), 1 if state_in else 0,
+                ws.data_ptr(), ws.numel(), bufs["out"].data_ptr(), bufs["out"].numel(),
+                bufs["sizes"].data_ptr(), bufs["offsets"].data_ptr())
+            self._check(rc)
+            for x in bufs.values():
+                if hasattr(x, "record_stream"):
+                    x.record_stream(cur)
+            return bufs
 
     def encode_to_host(self, fmt, pcm, num_packets, **kw):
         """Convenience for tests: returns (stream bytes ndarray, sizes ndarray)."""
@@ -246,49 +275,58 @@ class Context:
     def decode(self, cookie, stream, offsets, num_packets):
         """stream: uint8 cuda tensor, offsets: int64 cuda tensor [num_packets+1].
         Returns (pcm uint8 tensor [num_packets*packet_bytes], num_samples int32, status int32)."""
-        t = self.torch
-        ck = np.ascontiguousarray(cookie, np.uint8)
-        fmt = Format()
-        self._check(self.lib.alac_hip_format_from_cookie(ck.ctypes.data, ck.size, C.byref(fmt)))
-        pcm = t.zeros(num_packets * fmt.packet_bytes, dtype=t.uint8, device=self.device)
-        ns = t.zeros(num_packets, dtype=t.int32, device=self.device)
-        st = t.zeros(num_packets, dtype=t.int32, device=self.device)
-        # sized from the stream actually handed over (ID_FIL / ID_DSE padding may exceed the regular bound)
-        wsb = int(self.lib.alac_hip_decode_workspace_bytes_stream(C.byref(fmt), num_packets, int(stream.numel())))
-        ws = self._workspace(wsb)
-        rc = self.lib.alac_hip_decode(self.h, ck.ctypes.data, ck.size, stream.data_ptr(), offsets.data_ptr(),
-                                      num_packets, ws.data_ptr(), ws.numel(), pcm.data_ptr(), ns.data_ptr(),
-                                      st.data_ptr())
-        self._check(rc)
-        return pcm, ns, st, fmt
+        with self._call() as cur:
+            t = self.torch
+            ck = np.ascontiguousarray(cookie, np.uint8)
+            fmt = Format()
+            self._check(self.lib.alac_hip_format_from_cookie(ck.ctypes.data, ck.size, C.byref(fmt)))
+            pcm = t.zeros(num_packets * fmt.packet_bytes, dtype=t.uint8, device=self.device)
+            ns = t.zeros(num_packets, dtype=t.int32, device=self.device)
+            st = t.zeros(num_packets, dtype=t.int32, device=self.device)
+            # sized from the stream actually handed over (ID_FIL / ID_DSE padding may exceed the regular bound)
+            wsb = int(self.lib.alac_hip_decode_workspace_bytes_stream(C.byref(fmt), num_packets, int(stream.numel())))
+            ws = self._workspace(wsb)
+            rc = self.lib.alac_hip_decode(self.h, ck.ctypes.data, ck.size, stream.data_ptr(), offsets.data_ptr(),
+                                          num_packets, ws.data_ptr(), ws.numel(), pcm.data_ptr(), ns.data_ptr(),
+                                          st.data_ptr())
+            self._check(rc)
+            for x in (pcm, ns, st):
+                x.record_stream(cur)  # allocated on self.stream, consumed on the caller's
+            return pcm, ns, st, fmt
 
     # ---- stage level ------------------------------------------------------------------------
     def pc_block(self, x, num, coefs, numactive, chanbits, denshift=9, decode=False):
         """x: int32 cuda [rows, stride]; coefs: int16 cuda [rows, 32] (adapted in place)."""
-        t = self.torch
-        out = t.zeros_like(x)
-        fn = self.lib.alac_hip_unpc_block if decode else self.lib.alac_hip_pc_block
-        self._check(fn(self.h, x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], num,
-                       coefs.data_ptr(), numactive, chanbits, denshift))
-        return out
+        with self._call() as cur:
+            t = self.torch
+            out = t.zeros_like(x)
+            fn = self.lib.alac_hip_unpc_block if decode else self.lib.alac_hip_pc_block
+            self._check(fn(self.h, x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], num,
+                           coefs.data_ptr(), numactive, chanbits, denshift))
+            out.record_stream(cur)
+            return out
 
     def dyn_comp(self, pc, num_samples, bit_size, bytes_stride, mb0=10, pb=40, kb=14):
-        t = self.torch
-        rows = pc.shape[0]
-        bits = t.zeros((rows, bytes_stride), dtype=t.uint8, device=self.device)
-        nb = t.zeros(rows, dtype=t.int32, device=self.device)
-        self._check(self.lib.alac_hip_dyn_comp(self.h, mb0, pb, kb, pc.data_ptr(), rows, pc.shape[1],
-                                               num_samples, bit_size, bits.data_ptr(), bytes_stride,
-                                               nb.data_ptr()))
-        return bits, nb
+        with self._call() as cur:
+            t = self.torch
+            rows = pc.shape[0]
+            bits = t.zeros((rows, bytes_stride), dtype=t.uint8, device=self.device)
+            nb = t.zeros(rows, dtype=t.int32, device=self.device)
+            self._check(self.lib.alac_hip_dyn_comp(self.h, mb0, pb, kb, pc.data_ptr(), rows, pc.shape[1],
+                                                   num_samples, bit_size, bits.data_ptr(), bytes_stride,
+                                                   nb.data_ptr()))
+            bits.record_stream(cur)
+            nb.record_stream(cur)
+            return bits, nb
 
     def dyn_decomp(self, bits, num_samples, max_size, mb0=10, pb=40, kb=14):
-        t = self.torch
-        rows, stride = bits.shape
-        pc = t.zeros((rows, max(num_samples, 1)), dtype=t.int32, device=self.device)
-        nb = t.zeros(rows, dtype=t.int32, device=self.device)
-        st = t.zeros(rows, dtype=t.int32, device=self.device)
-        self._check(self.lib.alac_hip_dyn_decomp(self.h, mb0, pb, kb, bits.data_ptr(), stride, rows,
-                                                 pc.data_ptr(), pc.shape[1], num_samples, max_size,
-                                                 nb.data_ptr(), st.data_ptr()))
-        return pc, nb, st
+        with self._call() as cur:
+            t = self.torch
+            rows, stride = bits.shape
+            pc = t.zeros((rows, max(num_samples, 1)), dtype=t.int32, device=self.device)
+            nb = t.zeros(rows, dtype=t.int32, device=self.device)
+            st = t.zeros(rows, dtype=t.int32, device=self.device)
+            self._check(self.lib.alac_hip_dyn_decomp(self.h, mb0, pb, kb, bits.data_ptr(), stride, rows,
+                                                     pc.data_ptr(), pc.shape[1], num_samples, max_size,
+                                                     nb.data_ptr(), st.data_ptr()))
+            return pc, nb, st

@@ -225,9 +225,12 @@ def main():
                 state["pending"] = (ra.begin(b["out"], b["offsets"][-1:], b["sizes"]), b)
         return b
 
-    for i in range(args.warmup):
-        step(i)
-    finish_pending()
+    # the steps are issued ON the context's stream: the events step() records for the hand-over to the RCCL side stream are
+    # then ordered behind the encode without any cross-stream wait between two encodes
+    with torch.cuda.stream(ctx.stream):
+        for i in range(args.warmup):
+            step(i)
+        finish_pending()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -235,9 +238,10 @@ def main():
 
     ctx.profile_begin(args.steps)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    finish_pending()
+    with torch.cuda.stream(ctx.stream):
+        for i in range(args.steps):
+            last = step(args.warmup + i)
+        finish_pending()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
