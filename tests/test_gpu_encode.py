@@ -141,3 +141,29 @@ def test_rejects_bad_arguments(gpu_ctx):
     fmt = alac_amd.make_format(4096, 12, 2)
     with pytest.raises(Exception):
         gpu_ctx.encode(fmt, torch.zeros(1 << 16, dtype=torch.uint8).cuda(), 1)
+
+
+def test_throughput_regime_with_chained_segments(gpu_ctx, oracle):
+    """more than 65 536 chains (the throughput regime: separate launches, class compaction, 8 taps per lane) AND several
+    packets per segment: every position of every segment goes through the class layout; a sample of whole segments
+    (incl. the first, the last and the ones around a 1024-segment compaction block edge) must equal the oracle's chains"""
+    import torch
+    frame = 256
+    fmt = alac_amd.make_format(frame, 16, 2)
+    nseg = 34000
+    lens = np.where(np.arange(nseg) % 3 == 0, 3, 2).astype(np.int32)      # 2 or 3 packets per segment
+    seg_first = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    n = int(seg_first[-1])
+    pcm = alac_amd.synth_pcm(0, n, fmt)
+    ns = np.full(n, frame, np.int32)
+    ns[seg_first[1:] - 1] = np.where(np.arange(nseg) % 5 == 0, 100, frame)  # some segments end in a partial packet
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, num_samples=torch.from_numpy(ns).cuda(),
+                                           seg_first=torch.from_numpy(seg_first).cuda())
+    offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    enc = oracle.encoder(frame, 16, 2)
+    for s in [0, 1, 2, 5, 1022, 1023, 1024, 1025, 17000, 17001, 33995, 33998, 33999]:
+        enc.reset()
+        for p in range(seg_first[s], seg_first[s + 1]):
+            pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * fmt.bytes_per_frame], int(ns[p]))
+            assert sizes[p] == len(pk), (s, p)
+            assert np.array_equal(stream[offs[p]:offs[p + 1]], pk), (s, p)
