@@ -40,6 +40,11 @@ class Reassembler:
         self.rank = dist.get_rank(group)
         self.gloo = dist.get_backend(group) == "gloo"
         self.stream = None
+        # ALAC_REASSEMBLE=allgather (or a grouped send/receive that raises) falls back to the padded all-gather: every
+        # shard padded to the longest, one collective, then one copy per shard to its offset
+        import os
+        self.padded_mode = os.environ.get("ALAC_REASSEMBLE", "") == "allgather"
+        self.padded = None
 
     def begin(self, shard, length, sizes=None):
         """shard: 1-D uint8 tensor whose first `length` bytes are this rank's packets; length: int64 tensor with one
@@ -73,6 +78,20 @@ class Reassembler:
         total = int(offsets_h[-1].item())
         if self.stream is None or self.stream.numel() < total:
             self.stream = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+        if not self.padded_mode:
+            try:
+                self._place_direct(shard, lens_h, offsets_h, mine)
+            except RuntimeError as e:  # a backend without grouped point-to-point: keep the job alive on the collective
+                import sys
+                print(f"alac_amd.reassemble: grouped send/receive failed ({e}); falling back to the padded all-gather",
+                      file=sys.stderr)
+                self.padded_mode = True
+        if self.padded_mode:
+            self._place_padded(shard, lens_h, offsets_h)
+        return dict(stream=self.stream, total=total, lens=h["lens"], offsets=offsets_h, sizes=h["sizes"],
+                    mode="padded all-gather" if self.padded_mode else "grouped send/recv")
+
+    def _place_direct(self, shard, lens_h, offsets_h, mine):
         ops = []
         for r in range(self.world):
             n, o = int(lens_h[r].item()), int(offsets_h[r].item())
@@ -87,7 +106,17 @@ class Reassembler:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()  # NCCL: orders the current stream behind the group; gloo: blocks until it has completed
-        return dict(stream=self.stream, total=total, lens=h["lens"], offsets=offsets_h, sizes=h["sizes"])
+
+    def _place_padded(self, shard, lens_h, offsets_h):
+        pad = max((int(lens_h.max().item()) + 15) // 16 * 16, 16)
+        if pad > shard.numel():
+            raise ValueError("shard buffer shorter than the longest shard (padded all-gather)")
+        if self.padded is None or self.padded.numel() != self.world * pad:
+            self.padded = torch.empty(self.world * pad, dtype=torch.uint8, device=shard.device)
+        _all_gather_flat(self.padded, shard[:pad], self.group, self.gloo)
+        for r in range(self.world):
+            n, o = int(lens_h[r].item()), int(offsets_h[r].item())
+            self.stream[o:o + n].copy_(self.padded[r * pad:r * pad + n])
 
     def _peer(self, r):
         return r if self.group is None else dist.get_global_rank(self.group, r)

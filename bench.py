@@ -281,6 +281,7 @@ def main():
             pakt_ok = gather["sizes"] is not None and bool(torch.equal(gather["sizes"][rank * B:(rank + 1) * B], last["sizes"])) \
                 and int(gather["sizes"].to(torch.int64).sum().item()) == gather["total"]
             placement = {"shards_at_prefix_sum_offsets": placed, "packet_size_table_consistent": pakt_ok,
+                         "exchange": gather.get("mode"),
                          "stream_bytes": gather["total"], "shard_bytes": [int(x) for x in gather["lens"].cpu().tolist()]}
 
     if rank == 0:

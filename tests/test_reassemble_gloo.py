@@ -13,7 +13,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, per_rank, q):
+def _worker(rank, world, port, per_rank, q, mode=""):
+    os.environ["ALAC_REASSEMBLE"] = mode
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import alac_amd
@@ -48,8 +49,8 @@ def _worker(rank, world, port, per_rank, q):
 import pytest
 
 
-@pytest.mark.parametrize("WORLD", [2, 3])
-def test_rank_reassembly_equals_single_stream(WORLD):
+@pytest.mark.parametrize("WORLD,mode", [(2, ""), (3, ""), (2, "allgather")])
+def test_rank_reassembly_equals_single_stream(WORLD, mode):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import alac_amd
     from oracle_lib import Oracle
@@ -57,7 +58,7 @@ def test_rank_reassembly_equals_single_stream(WORLD):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per_rank, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in range(world)]
