@@ -273,11 +273,15 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
             if (jb + B <= R.split || jb >= R.split) {
                 const bool first = jb + B <= R.split;
                 const uint64_t st = first ? R.s0 : R.s1;
-                const int32_t *row = (first ? R.p0 : R.p1) + (uint64_t)jb * st;
+                // scalar row base + the lane's 32-bit byte offset: a global load with an SGPR base and a VGPR offset, no
+                // 64-bit vector address arithmetic per row
+                const char *base = (const char *)((first ? R.p0 : R.p1) + (uint64_t)jb * st);
+                const uint32_t rowBytes = (uint32_t)st * 4u;  // < 2^32: a row is at most 5 planes x chains x 4 bytes
+                uint32_t off = R.col * 4u;                     // 16 rows stay below 2^32 bytes as well
 #pragma unroll
                 for (int s = 0; s < B; s++) {
-                    buf[s] = row[R.col];
-                    row += st;
+                    buf[s] = *(const int32_t *)(base + off);
+                    off += rowBytes;
                 }
             } else {  // the block straddles the split (never with 4096-sample packets: split = 128)
 #pragma unroll
