@@ -7,11 +7,13 @@
 //   k_scan_sizes                      device-wide exclusive scan of the packet sizes
 //   k_pack                            one workgroup per packet: header + shift-off bytes + U bits
 //                                     + V bits (+ escape payload) funnel-shifted into the packed
-//                                     byte-aligned stream at the scanned offset
+//                                     byte-aligned stream at the scanned offset; every wave issues all
+//                                     its loads before its first store (one memory round trip)
 //
 // Reference control flow restated: ALACEncoder::EncodeStereo codec/ALACEncoder.cu:290-558,
 // EncodeStereoEscape :749-806, EncodeMono :812-963, Encode :973-1057.
 #include <cstdlib>
+#include <type_traits>
 #include "alac_dev.hpp"
 #include "alac_kernels.hpp"
 
@@ -441,60 +443,30 @@ __device__ __forceinline__ uint32_t take(Fetch &&fetch32, uint64_t len, int64_t 
     return fetch32(0) >> (uint32_t)(-s);
 }
 
-// MSB-first bit writer over zero-initialised 32-bit words, one word-sized step per field (the header is built by
-// one lane while the rest of the workgroup waits: keep it short)
-struct HdrWriter {
-    uint32_t *w;
-    uint32_t pos;
-    __device__ __forceinline__ void put(uint32_t v, uint32_t n)
-    {
-        // n <= 32; v confined to n bits by the callers
-        const uint32_t i = pos >> 5, o = pos & 31;
-        const uint64_t x = ((uint64_t)v << (64 - n)) >> o;  // field left-aligned at bit o of a 64-bit window
-        w[i] |= (uint32_t)(x >> 32);
-        if (o + n > 32) w[i + 1] |= (uint32_t)x;
-        pos += n;
-    }
-};
-
 template <int DEPTH, int CH>
-__global__ __launch_bounds__(256) void k_pack(PackArgs A)
+__global__ __launch_bounds__(256) void k_pack(PackArgs A, uint32_t numPackets)
 {
-    __shared__ uint32_t hdr[16];
-    const uint32_t p = blockIdx.x;
-    const PacketRec rec = A.recs[p];
+    // A workgroup walks packets blockIdx.x, blockIdx.x + gridDim.x, ...: with one workgroup per packet the launch was
+    // bound by workgroup DISPATCH (125 000 empty 256-thread workgroups alone take 0.6 ms, measured), not by the copy.
+    // Nothing in the loop synchronises the workgroup: waves 0..2 only copy, the last wave builds the header (its lanes
+    // are the header's fields), writes the few words around the spans, then joins the copy.
+    __shared__ uint32_t hdr[16];  // touched by the last wave only: LDS operations of one wave execute in order
+    const uint32_t lane = threadIdx.x & 63;
+    const bool seamWave = (threadIdx.x >> 6) == (blockDim.x >> 6) - 1;
+    constexpr uint32_t SHB = bytes_shifted(DEPTH);
+    PacketRec recNext = A.recs[blockIdx.x];
+    uint64_t offNext = A.offsets[blockIdx.x];
+    for (uint32_t p = blockIdx.x; p < numPackets; p += gridDim.x) {
+    // this packet's record and offset were requested one packet ago
+    const PacketRec rec = recNext;
+    const uint64_t outOff = offNext;
+    if (p + gridDim.x < numPackets) {
+        recNext = A.recs[p + gridDim.x];
+        offNext = A.offsets[p + gridDim.x];
+    }
     const uint32_t N = rec.numSamples;
     const uint32_t partial = (N != A.frameSize);
-    constexpr uint32_t SHB = bytes_shifted(DEPTH);
     const uint8_t *pk = A.pcm + (uint64_t)p * A.frameSize * CH * bytes_per_sample(DEPTH);
-
-    if (threadIdx.x < 16) hdr[threadIdx.x] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // Encode() :989-991 / :1011-1012 element tag, then the element header
-        HdrWriter h{hdr, 0};
-        h.put(CH == 2 ? 1u : 0u, 3);
-        h.put(0, 4);
-        h.put(0, 12);
-        if (rec.escape) {
-            h.put((partial << 3) | 1u, 4);  // :762
-            if (partial) h.put(N, 32);
-        } else {
-            h.put((partial << 3) | (SHB << 1), 4);  // :467 / :921
-            if (partial) h.put(N, 32);
-            if (CH == 2) {
-                h.put((uint32_t)kMixBits, 8);
-                h.put(rec.mixRes, 8);
-            } else {
-                h.put(0, 16);
-            }
-            for (int c = 0; c < CH; c++) {
-                h.put((0u << 4) | kDenShift, 8);
-                h.put((4u << 5) | rec.c[c].num, 8);
-                for (uint32_t k = 0; k < rec.c[c].num; k++) h.put((uint16_t)rec.c[c].coefs[k], 16);
-            }
-        }
-    }
     // the header LENGTH follows from the record alone, so the bulk copies below need not wait for its bits
     uint32_t hb = 3 + 4 + 12 + 4 + (partial ? 32u : 0u);
     if (!rec.escape) {
@@ -515,187 +487,190 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
 
     const uint32_t *wU = A.bitWords + (uint64_t)p * 2 * A.wcap;
     const uint32_t *wV = wU + A.wcap;
-    const uint64_t outOff = A.offsets[p];
     const uint32_t mis = (uint32_t)(outOff & 15);  // work in words of a 16-byte aligned frame: 16-byte stores
     uint8_t *outAligned = A.out + (outOff - mis);
     const uint32_t nwords = (mis + nb + 3) / 4;
 
     auto sampleField = [&](uint32_t t) -> uint32_t { return (uint32_t)load_sample<DEPTH>(pk, t); };
 
-    // Bulk of a packet = the two channel bit strings (or the raw samples of an escape packet): output words that
-    // lie completely inside one of them are a plain funnel-shifted copy with a constant shift — no per-word
-    // segment search, independent loads.  Words touching a segment boundary (header, U|V seam, tail; a dozen per
-    // packet) and the 24-bit shift bytes take the general path below.
+    // Bulk of a packet = the two channel bit strings (or the raw samples of an escape packet): the 16-byte groups of
+    // output words that lie completely inside one of them are a plain funnel-shifted copy with a constant shift — no
+    // per-word segment search, independent loads, ONE memory round trip per wave.  Every other word (header, up to three
+    // words either side of a span, the tail) is a seam word of the last wave, below.
     struct Span {
-        uint32_t w0, w1;  // aligned output words [w0, w1) fully inside the segment
+        uint32_t w0, w1;  // aligned output words [w0, w1), both multiples of four, fully inside the segment
     };
     auto span_of = [&](int64_t off, uint64_t len) {
         const int64_t base = off + (int64_t)mis * 8;  // bit position from the aligned output start
         Span sp;
-        sp.w0 = (uint32_t)((base + 31) >> 5);
-        sp.w1 = (uint32_t)((base + (int64_t)len) >> 5);
+        sp.w0 = ((uint32_t)((base + 31) >> 5) + 3) & ~3u;
+        sp.w1 = (uint32_t)((base + (int64_t)len) >> 5) & ~3u;
         if (sp.w1 < sp.w0) sp.w1 = sp.w0;
         return sp;
     };
-    auto copy_span = [&](const Span &sp, int64_t off, auto &&srcWord) {
-        const uint32_t sh = (uint32_t)((int64_t)sp.w0 * 32 - (off + (int64_t)mis * 8));  // 0..31: source bit of word w0
-        auto one = [&](uint32_t w) {
-            const uint32_t i = w - sp.w0;
-            const uint32_t a = srcWord(i);
-            const uint32_t b = sh ? srcWord(i + 1) : 0u;  // exists: the output word ends inside the segment
-            const uint32_t v = sh ? __builtin_amdgcn_alignbit(a, b, 32 - sh) : a;
-            *(uint32_t *)(outAligned + (uint64_t)w * 4) = __builtin_bswap32(v);
-        };
-        // groups of four words = one 16-byte store, five independent loads in flight per lane (the copy is
-        // latency bound: bytes in flight per lane are what sets its rate)
-        const uint32_t g0 = (sp.w0 + 3) & ~3u, g1 = sp.w1 & ~3u;
-        if (g0 < g1) {
-            for (uint32_t w = sp.w0 + threadIdx.x; w < g0; w += blockDim.x) one(w);
-            for (uint32_t w = g0 + 4 * threadIdx.x; w < g1; w += 4 * blockDim.x) {
-                const uint32_t i = w - sp.w0;
-                uint32_t a[5];
-#pragma unroll
-                for (int q = 0; q < 5; q++) a[q] = (q < 4 || sh) ? srcWord(i + q) : 0u;
-                uint4 v;
-                v.x = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[0], a[1], 32 - sh) : a[0]);
-                v.y = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[1], a[2], 32 - sh) : a[1]);
-                v.z = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[2], a[3], 32 - sh) : a[2]);
-                v.w = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[3], a[4], 32 - sh) : a[3]);
-                *(uint4 *)(outAligned + (uint64_t)w * 4) = v;
+    // output word w of a span = source bits [32 (w - w0) + first, + 32) of its segment
+    auto first_bit = [&](const Span &sp, int64_t off) { return (uint32_t)((int64_t)sp.w0 * 32 - (off + (int64_t)mis * 8)); };
+    auto load5 = [&](uint32_t a[5], bool have, uint32_t i, uint32_t sh, auto &&src) {
+        if constexpr (std::is_pointer_v<std::decay_t<decltype(src)>>) {
+            // a word string in memory: one 16-byte load (the address is only dword aligned, which global loads
+            // allow) + one dword instead of five dword loads — a third of the cache accesses
+            typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+            const char *at = (const char *)src + i * 4u;  // 32-bit offset from a uniform base
+            U4 v = {0, 0, 0, 0};
+            uint32_t e = 0;
+            if (have) {
+                v = *(const U4 *)at;
+                if (sh) e = *(const uint32_t *)(at + 16);
             }
-            for (uint32_t w = g1 + threadIdx.x; w < sp.w1; w += blockDim.x) one(w);
+            a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w, a[4] = e;
         } else {
-            for (uint32_t w = sp.w0 + threadIdx.x; w < sp.w1; w += blockDim.x) one(w);
+#pragma unroll
+            for (int q = 0; q < 5; q++) a[q] = (have && (q < 4 || sh)) ? src(i + q) : 0u;
         }
     };
-    // Two spans at once (the U and the V bit string of a stereo packet): the loads of BOTH are issued before either is
-    // stored, so the packet pays one memory round trip for its bulk instead of two — the packer is bound by the chain of
-    // dependent round trips per workgroup (record -> spans -> seams), not by bandwidth.
-    auto copy_two = [&](const Span &sa, int64_t offA, auto &&srcA, const Span &sb, int64_t offB, auto &&srcB) {
-        const uint32_t shA = (uint32_t)((int64_t)sa.w0 * 32 - (offA + (int64_t)mis * 8));
-        const uint32_t shB = (uint32_t)((int64_t)sb.w0 * 32 - (offB + (int64_t)mis * 8));
-        auto oneOf = [&](const Span &sp, uint32_t sh, auto &&src, uint32_t w) {
-            const uint32_t i = w - sp.w0;
-            const uint32_t a = src(i);
-            const uint32_t b = sh ? src(i + 1) : 0u;
-            *(uint32_t *)(outAligned + (uint64_t)w * 4) = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a, b, 32 - sh) : a);
-        };
-        const uint32_t ga0 = min((sa.w0 + 3) & ~3u, sa.w1), ga1 = max(sa.w1 & ~3u, ga0);
-        const uint32_t gb0 = min((sb.w0 + 3) & ~3u, sb.w1), gb1 = max(sb.w1 & ~3u, gb0);
-        const uint32_t na = (ga1 - ga0) / 4, nb2 = (gb1 - gb0) / 4;
-        for (uint32_t g = threadIdx.x; g < max(na, nb2); g += blockDim.x) {
-            const bool ha = g < na, hb = g < nb2;
-            const uint32_t wa = ga0 + 4 * g, wb = gb0 + 4 * g;
-            const uint32_t ia = wa - sa.w0, ib = wb - sb.w0;
-            uint32_t a[5], b[5];
+    auto store4 = [&](const uint32_t a[5], uint32_t sh, uint32_t w) {
+        uint4 v;
+        v.x = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[0], a[1], 32 - sh) : a[0]);
+        v.y = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[1], a[2], 32 - sh) : a[1]);
+        v.z = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[2], a[3], 32 - sh) : a[2]);
+        v.w = __builtin_bswap32(sh ? __builtin_amdgcn_alignbit(a[3], a[4], 32 - sh) : a[3]);
+        *(uint4 *)(outAligned + (uint64_t)w * 4) = v;
+    };
+    auto copy_span = [&](const Span &sp, int64_t off, auto &&srcWord) {
+        const uint32_t fb = first_bit(sp, off), i0 = fb >> 5, sh = fb & 31;
+        // five independent loads in flight per lane and 16-byte store
+        for (uint32_t w = sp.w0 + 4 * threadIdx.x; w < sp.w1; w += 4 * blockDim.x) {
+            uint32_t a[5];
+            load5(a, true, i0 + (w - sp.w0), sh, srcWord);
+            store4(a, sh, w);
+        }
+    };
+    // The spans of a compressed packet at once — shift-off bytes (24- / 32-bit), U bits, V bits (stereo): the loads of
+    // ALL are issued before anything is stored, so a wave pays one memory round trip for its share of the packet.
+    // Shift-off bytes (codec/ALACEncoder.cu:489-503) = the low SHB bytes of every channel sample, MSB first:
+    // 24-bit: one byte per 3-byte sample, four samples (three PCM dwords) per output word, read as three 16-byte loads
+    // per group of four words; 32-bit: two bytes per sample, two samples (two PCM dwords) per output word.
+    typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto shift_word24 = [](uint32_t d0, uint32_t d1, uint32_t d2) {
+        return (d0 << 24) | ((d0 >> 24) << 16) | (((d1 >> 16) & 0xffu) << 8) | ((d2 >> 8) & 0xffu);
+    };
+    auto shift_word_slow = [&](uint32_t i) -> uint32_t {  // a word at the ragged end of the samples
+        const uint32_t fields = N * CH;
+        if constexpr (DEPTH == 24) {
+            uint32_t v = 0;
+            for (uint32_t q = 0; q < 4; q++)
+                v = (v << 8) | (4 * i + q < fields ? ((uint32_t)load_sample<24>(pk, 4 * i + q) & 0xffu) : 0u);
+            return v;
+        } else {
+            const uint32_t *pw = (const uint32_t *)pk;
+            const uint32_t t = 2 * i;
+            const uint32_t a = t < fields ? pw[t] : 0u, b = t + 1 < fields ? pw[t + 1] : 0u;
+            return (a << 16) | (b & 0xffffu);
+        }
+    };
+    // source words i .. i + 3 are complete (the output group lies inside the segment); i + 4 may be ragged
+    auto load5_shift = [&](uint32_t a[5], bool have, uint32_t i, uint32_t sh) {
+        const uint32_t *pw = (const uint32_t *)pk;  // packets are dword aligned for these depths (frame * 6 or 8 bytes)
+        const uint32_t fields = N * CH;
 #pragma unroll
-            for (int q = 0; q < 5; q++) a[q] = (ha && (q < 4 || shA)) ? srcA(ia + q) : 0u;
-#pragma unroll
-            for (int q = 0; q < 5; q++) b[q] = (hb && (q < 4 || shB)) ? srcB(ib + q) : 0u;
-            if (ha) {
-                uint4 v;
-                v.x = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[0], a[1], 32 - shA) : a[0]);
-                v.y = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[1], a[2], 32 - shA) : a[1]);
-                v.z = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[2], a[3], 32 - shA) : a[2]);
-                v.w = __builtin_bswap32(shA ? __builtin_amdgcn_alignbit(a[3], a[4], 32 - shA) : a[3]);
-                *(uint4 *)(outAligned + (uint64_t)wa * 4) = v;
+        for (int q = 0; q < 5; q++) a[q] = 0;
+        if (!have) return;
+        if constexpr (DEPTH == 24) {
+            const char *at = (const char *)pw + i * 12u;
+            const U4 x = *(const U4 *)at, y = *(const U4 *)(at + 16), z = *(const U4 *)(at + 32);
+            a[0] = shift_word24(x.x, x.y, x.z);
+            a[1] = shift_word24(x.w, y.x, y.y);
+            a[2] = shift_word24(y.z, y.w, z.x);
+            a[3] = shift_word24(z.y, z.z, z.w);
+            if (sh) {
+                if (4 * (i + 4) + 4 <= fields) {
+                    const uint32_t d0 = *(const uint32_t *)(at + 48), d1 = *(const uint32_t *)(at + 52), d2 = *(const uint32_t *)(at + 56);
+                    a[4] = shift_word24(d0, d1, d2);
+                } else {
+                    a[4] = shift_word_slow(i + 4);
+                }
             }
-            if (hb) {
-                uint4 v;
-                v.x = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[0], b[1], 32 - shB) : b[0]);
-                v.y = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[1], b[2], 32 - shB) : b[1]);
-                v.z = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[2], b[3], 32 - shB) : b[2]);
-                v.w = __builtin_bswap32(shB ? __builtin_amdgcn_alignbit(b[3], b[4], 32 - shB) : b[3]);
-                *(uint4 *)(outAligned + (uint64_t)wb * 4) = v;
+        } else {
+            const char *at = (const char *)pw + i * 8u;
+            const U4 x = *(const U4 *)at, y = *(const U4 *)(at + 16);
+            a[0] = (x.x << 16) | (x.y & 0xffffu);
+            a[1] = (x.z << 16) | (x.w & 0xffffu);
+            a[2] = (y.x << 16) | (y.y & 0xffffu);
+            a[3] = (y.z << 16) | (y.w & 0xffffu);
+            if (sh) {
+                if (2 * (i + 4) + 2 <= fields) {
+                    const uint32_t d0 = *(const uint32_t *)(at + 32), d1 = *(const uint32_t *)(at + 36);
+                    a[4] = (d0 << 16) | (d1 & 0xffffu);
+                } else {
+                    a[4] = shift_word_slow(i + 4);
+                }
             }
         }
-        // the few words in front of / behind the 16-byte groups
-        for (uint32_t w = sa.w0 + threadIdx.x; w < ga0; w += blockDim.x) oneOf(sa, shA, srcA, w);
-        for (uint32_t w = ga1 + threadIdx.x; w < sa.w1; w += blockDim.x) oneOf(sa, shA, srcA, w);
-        for (uint32_t w = sb.w0 + threadIdx.x; w < gb0; w += blockDim.x) oneOf(sb, shB, srcB, w);
-        for (uint32_t w = gb1 + threadIdx.x; w < sb.w1; w += blockDim.x) oneOf(sb, shB, srcB, w);
+    };
+    auto copy_bulk = [&](const Span &ss, const Span &sa, const Span &sb) {
+        constexpr bool SHIFT = SHB != 0 && (DEPTH == 24 || DEPTH == 32);
+        const uint32_t fs = first_bit(ss, offShift), is0 = fs >> 5, shS = fs & 31;
+        const uint32_t fa = first_bit(sa, offU), ia0 = fa >> 5, shA = fa & 31;
+        const uint32_t fb = first_bit(sb, offV), ib0 = fb >> 5, shB = fb & 31;
+        const uint32_t ns = SHIFT ? (ss.w1 - ss.w0) / 4 : 0u, na = (sa.w1 - sa.w0) / 4, nb2 = CH == 2 ? (sb.w1 - sb.w0) / 4 : 0u;
+        for (uint32_t g = threadIdx.x; g < max(ns, max(na, nb2)); g += blockDim.x) {
+            const bool hs = g < ns, ha = g < na, hb = g < nb2;
+            uint32_t x[5], a[5], b[5];
+            if constexpr (SHIFT) load5_shift(x, hs, is0 + 4 * g, shS);
+            load5(a, ha, ia0 + 4 * g, shA, wU);
+            if constexpr (CH == 2) load5(b, hb, ib0 + 4 * g, shB, wV);
+            if constexpr (SHIFT)
+                if (hs) store4(x, shS, ss.w0 + 4 * g);
+            if (ha) store4(a, shA, sa.w0 + 4 * g);
+            if constexpr (CH == 2)
+                if (hb) store4(b, shB, sb.w0 + 4 * g);
+        }
     };
     Span spU = {0, 0}, spV = {0, 0}, spR = {0, 0}, spS = {0, 0};
     if (!rec.escape) {
-        if constexpr (SHB != 0 && (DEPTH == 24 || DEPTH == 32)) {
-            // shift-off bytes (codec/ALACEncoder.cu:489-503): the low SHB bytes of every channel sample, MSB first.
-            // 24-bit: one byte per 3-byte sample, four samples (three PCM dwords) per output word;
-            // 32-bit: two bytes per sample, two samples (two PCM dwords) per output word.
-            spS = span_of(offShift, lenShift);
-            const uint32_t *pw = (const uint32_t *)pk;  // packets are dword aligned for these depths (frame * 6 or 8 bytes)
-            const uint32_t fields = N * CH;             // samples; the last word may hold fewer than a full group
-            copy_span(spS, offShift, [&](uint32_t i) -> uint32_t {
-                if constexpr (DEPTH == 24) {
-                    const uint32_t t = 4 * i;
-                    if (t + 4 <= fields) {
-                        const uint32_t w0 = pw[3 * i], w1 = pw[3 * i + 1], w2 = pw[3 * i + 2];
-                        return (w0 << 24) | ((w0 >> 24) << 16) | (((w1 >> 16) & 0xffu) << 8) | ((w2 >> 8) & 0xffu);
-                    }
-                    uint32_t v = 0;
-                    for (uint32_t q = 0; q < 4; q++)
-                        v = (v << 8) | (t + q < fields ? ((uint32_t)load_sample<24>(pk, t + q) & 0xffu) : 0u);
-                    return v;
-                } else {
-                    const uint32_t t = 2 * i;
-                    const uint32_t a = t < fields ? pw[t] : 0u, b = t + 1 < fields ? pw[t + 1] : 0u;
-                    return (a << 16) | (b & 0xffffu);
-                }
-            });
-        }
+        if constexpr (SHB != 0 && (DEPTH == 24 || DEPTH == 32)) spS = span_of(offShift, lenShift);
         spU = span_of(offU, lenU);
-        if constexpr (CH == 2) {
-            spV = span_of(offV, lenV);
-            copy_two(spU, offU, [&](uint32_t i) { return wU[i]; }, spV, offV, [&](uint32_t i) { return wV[i]; });
-        } else {
-            copy_span(spU, offU, [&](uint32_t i) { return wU[i]; });
-        }
-    } else if constexpr (DEPTH == 16) {
-        // raw 16-bit samples, MSB first: two little-endian samples per PCM word, swapped into place by a rotate
+        if constexpr (CH == 2) spV = span_of(offV, lenV);
+    } else {
         spR = span_of(offRaw, lenRaw);
-        const uint32_t *pw = (const uint32_t *)pk;  // 16-byte aligned packet (checked by the C entry point)
-        copy_span(spR, offRaw, [&](uint32_t i) {
-            const uint32_t x = pw[i];
-            return (x << 16) | (x >> 16);
-        });
-    } else if constexpr (DEPTH == 32) {
-        // raw 32-bit samples, MSB first: the word IS the little-endian sample
-        spR = span_of(offRaw, lenRaw);
-        const uint32_t *pw = (const uint32_t *)pk;
-        copy_span(spR, offRaw, [&](uint32_t i) { return pw[i]; });
-    } else if constexpr (DEPTH == 24) {
-        // raw 24-bit samples, MSB first: four samples (PCM bytes B0..B11 in three dwords) make three words
-        // B2 B1 B0 B5 | B4 B3 B8 B7 | B6 B11 B10 B9
-        spR = span_of(offRaw, lenRaw);
-        const uint32_t *pw = (const uint32_t *)pk;
-        const uint32_t ndw = (N * CH * 3 + 3) / 4;  // dwords that hold samples (the tail of the last one is padding)
-        copy_span(spR, offRaw, [&](uint32_t i) -> uint32_t {
-            const uint32_t g = i / 3, r = i - 3 * g;
-            const uint32_t d0 = 3 * g < ndw ? pw[3 * g] : 0u, d1 = 3 * g + 1 < ndw ? pw[3 * g + 1] : 0u,
-                           d2 = 3 * g + 2 < ndw ? pw[3 * g + 2] : 0u;
-            if (r == 0) return ((d0 << 8) & 0xff000000u) | ((d0 << 8) & 0x00ff0000u) | ((d0 << 8) & 0x0000ff00u) | ((d1 >> 8) & 0xffu);
-            if (r == 1) return (d1 << 24) | ((d0 >> 24) << 16) | ((d2 & 0xffu) << 8) | (d1 >> 24);
-            return (((d1 >> 16) & 0xffu) << 24) | ((d2 >> 24) << 16) | (((d2 >> 16) & 0xffu) << 8) | ((d2 >> 8) & 0xffu);
-        });
     }
-
-    __syncthreads();  // header words complete
-    for (uint32_t aw = threadIdx.x; aw < nwords; aw += blockDim.x) {
-        if ((aw >= spU.w0 && aw < spU.w1) || (aw >= spV.w0 && aw < spV.w1) || (aw >= spR.w0 && aw < spR.w1) ||
-            (aw >= spS.w0 && aw < spS.w1))
-            continue;
-        const int64_t bp = (int64_t)aw * 32 - (int64_t)mis * 8;
-        uint32_t v = take([&](uint64_t s0) { return words_fetch32(hdr, (uint32_t)lenHdr, (uint32_t)s0); }, lenHdr, bp);
-        if (!rec.escape) {
-            if constexpr (SHB != 0)
-                v |= take([&](uint64_t s0) { return fields_fetch32<SHB * 8>(sampleField, N * CH, s0); }, lenShift, bp - offShift);
-            v |= take([&](uint64_t s0) { return words_fetch32(wU, (uint32_t)lenU, (uint32_t)s0); }, lenU, bp - offU);
-            if constexpr (CH == 2)
-                v |= take([&](uint64_t s0) { return words_fetch32(wV, (uint32_t)lenV, (uint32_t)s0); }, lenV, bp - offV);
-        } else {
-            v |= take([&](uint64_t s0) { return fields_fetch32<DEPTH>(sampleField, N * CH, s0); }, lenRaw, bp - offRaw);
-        }
-        v |= take([](uint64_t s0) { return 0xE0000000u << (uint32_t)s0; }, 3, bp - offEnd);
-
+    // Seam words = the words no span covers: in front of the first span (header), between spans, the tail with ID_END.
+    // Lane k of the last wave owns seam word k; its operands from the U and V bit strings are requested BEFORE the
+    // wave takes part in the bulk copy and combined after it, so the wave pays one memory round trip per packet, too.
+    const Span s1 = rec.escape ? spR : spS, s2 = spU, s3 = spV;  // in stream order, empty ones have w1 == w0
+    const uint32_t nSeam = nwords - (s1.w1 - s1.w0) - (s2.w1 - s2.w0) - (s3.w1 - s3.w0);
+    auto seam_word = [&](uint32_t k) {
+        uint32_t aw = k;
+        if (aw >= s1.w0) aw += s1.w1 - s1.w0;
+        if (aw >= s2.w0) aw += s2.w1 - s2.w0;
+        if (aw >= s3.w0) aw += s3.w1 - s3.w0;
+        return aw;
+    };
+    // 32 bits of a word string from bit s (may be negative / beyond the end): both candidate words, clamped, no branch
+    struct Pair {
+        uint32_t a, b;
+    };
+    auto fetch_pair = [&](const uint32_t *w, uint64_t len, int64_t s) {
+        const uint32_t nw = (uint32_t)((len + 31) >> 5);
+        const uint32_t i = s > 0 ? (uint32_t)(s >> 5) : 0u;
+        const uint32_t last = nw ? nw - 1 : 0u;
+        Pair pr;
+        pr.a = w[min(i, last)];
+        pr.b = w[min(i + 1, last)];
+        return pr;
+    };
+    auto combine_pair = [&](const Pair &pr, uint64_t len, int64_t s) -> uint32_t {
+        if (s >= (int64_t)len || s <= -32) return 0u;
+        const uint32_t s0 = s > 0 ? (uint32_t)s : 0u;
+        const uint32_t i = s0 >> 5, sh = s0 & 31;
+        const uint32_t nw = (uint32_t)((len + 31) >> 5);
+        const uint32_t b = (i + 1 < nw) ? pr.b : 0u;
+        uint32_t v = sh ? ((pr.a << sh) | (b >> (32 - sh))) : pr.a;
+        const uint32_t rem = (uint32_t)len - s0;
+        if (rem < 32) v &= ~0u << (32 - rem);
+        return s < 0 ? v >> (uint32_t)(-s) : v;
+    };
+    auto seam_store = [&](uint32_t aw, uint32_t v) {
         const int64_t b0 = (int64_t)aw * 4 - mis;  // packet byte index of this word's first byte
         if (b0 >= 0 && b0 + 4 <= (int64_t)nb) {
             *(uint32_t *)(outAligned + (uint64_t)aw * 4) = __builtin_bswap32(v);
@@ -706,7 +681,212 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A)
                 if (pb >= 0 && pb < (int64_t)nb) outAligned[(uint64_t)aw * 4 + b] = (uint8_t)(v >> (24 - 8 * b));
             }
         }
+    };
+    // 32 bits of the shift-off byte string from bit s0 (0 <= s0 < lenShift): both source words requested at once
+    auto shift_fetch32 = [&](uint32_t s0) -> uint32_t {
+        if constexpr (SHB == 0) {
+            return 0u;
+        } else if constexpr (DEPTH != 24 && DEPTH != 32) {
+            return fields_fetch32<SHB * 8>(sampleField, N * CH, s0);
+        } else {
+            const uint32_t *pw = (const uint32_t *)pk;
+            const uint32_t fields = N * CH, perWord = DEPTH == 24 ? 4u : 2u, dwPerWord = DEPTH == 24 ? 3u : 2u;
+            const uint32_t i = s0 >> 5, sh = s0 & 31;
+            const uint32_t nFull = fields / perWord;  // complete source words
+            const bool fullA = i < nFull, fullB = i + 1 < nFull;
+            // clamped, unconditional: the ragged last word (if any) takes the slow path afterwards
+            const uint32_t ia = fullA ? i : 0u, ib = fullB ? i + 1 : 0u;
+            uint32_t da[3], db[3];
+#pragma unroll
+            for (uint32_t q = 0; q < dwPerWord; q++) da[q] = nFull ? pw[ia * dwPerWord + q] : 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < dwPerWord; q++) db[q] = nFull ? pw[ib * dwPerWord + q] : 0u;
+            uint32_t a, b;
+            if constexpr (DEPTH == 24) {
+                a = shift_word24(da[0], da[1], da[2]);
+                b = shift_word24(db[0], db[1], db[2]);
+            } else {
+                a = (da[0] << 16) | (da[1] & 0xffffu);
+                b = (db[0] << 16) | (db[1] & 0xffffu);
+            }
+            if (!fullA) a = shift_word_slow(i);
+            if (!fullB) b = shift_word_slow(i + 1);  // zero beyond the samples
+            uint32_t v = sh ? ((a << sh) | (b >> (32 - sh))) : a;
+            const uint32_t rem = (uint32_t)lenShift - s0;
+            if (rem < 32) v &= ~0u << (32 - rem);
+            return v;
+        }
+    };
+    // everything of a seam word except the U / V operands
+    auto seam_rest = [&](int64_t bp) {
+        uint32_t v = take([&](uint64_t s0) { return words_fetch32(hdr, (uint32_t)lenHdr, (uint32_t)s0); }, lenHdr, bp);
+        if (!rec.escape) {
+            if constexpr (SHB != 0)
+                v |= take([&](uint64_t s0) { return shift_fetch32((uint32_t)s0); }, lenShift, bp - offShift);
+        } else {
+            v |= take([&](uint64_t s0) { return fields_fetch32<DEPTH>(sampleField, N * CH, s0); }, lenRaw, bp - offRaw);
+        }
+        v |= take([](uint64_t s0) { return 0xE0000000u << (uint32_t)s0; }, 3, bp - offEnd);
+        return v;
+    };
+    Pair seamU = {0, 0}, seamV = {0, 0};
+    const uint32_t seamAw = seam_word(lane);
+    const int64_t seamBp = (int64_t)seamAw * 32 - (int64_t)mis * 8;
+    if (seamWave) {
+        // ---- header (Encode() :989-991 / :1011-1012 element tag, then the element header): one lane per field, OR-ed
+        // into zeroed LDS words.  lane 0: tag 3 | 0 4 | 0 12 | flags 4 (:467 / :762 / :921); lane 1: numSamples of a
+        // partial frame; lane 2: mixBits | mixRes; per channel c: lane 3 + 9c = (mode|denShift, pbFactor|num), lanes
+        // 4 + 9c + k = coefficient k (picked out of the record's registers by a select chain: no load).
+        if (lane < 16) hdr[lane] = 0;
+        uint32_t fpos = 0, fn = 0, fv = 0;
+        const uint32_t base = 23 + (partial ? 32u : 0u);
+        if (lane == 0) {
+            fn = 23;
+            fv = ((CH == 2 ? 1u : 0u) << 20) | (rec.escape ? ((partial << 3) | 1u) : ((partial << 3) | (SHB << 1)));
+        } else if (lane == 1) {
+            fpos = 23, fn = partial ? 32u : 0u, fv = N;
+        } else if (!rec.escape) {
+            if (lane == 2) {
+                fpos = base, fn = 16, fv = CH == 2 ? (((uint32_t)kMixBits << 8) | (rec.mixRes & 0xffu)) : 0u;
+            } else if (lane < 3 + 9 * CH) {
+                const uint32_t c = (lane - 3) / 9, k = (lane - 3) - 9 * c;
+                const uint32_t num = c ? rec.c[CH - 1].num : rec.c[0].num;
+                const uint32_t cstart = base + 16 + (c ? 16 + 16 * (uint32_t)rec.c[0].num : 0u);
+                if (k == 0) {
+                    fpos = cstart, fn = 16, fv = (((0u << 4) | kDenShift) << 8) | ((4u << 5) | num);
+                } else if (k - 1 < num) {
+                    uint32_t coef = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t cq = (uint16_t)(c ? rec.c[CH - 1].coefs[q] : rec.c[0].coefs[q]);
+                        coef = (k - 1 == (uint32_t)q) ? cq : coef;
+                    }
+                    fpos = cstart + 16 * k, fn = 16, fv = coef;
+                }
+            }
+        }
+        if (fn) {
+            const uint32_t i = fpos >> 5, o = fpos & 31;
+            const uint64_t x = ((uint64_t)fv << (64 - fn)) >> o;  // field left-aligned at bit o of a 64-bit window
+            atomicOr(&hdr[i], (uint32_t)(x >> 32));
+            if (o + fn > 32) atomicOr(&hdr[i + 1], (uint32_t)x);
+        }
+        if (!rec.escape && lane < nSeam) {
+            seamU = fetch_pair(wU, lenU, seamBp - offU);
+            if constexpr (CH == 2) seamV = fetch_pair(wV, lenV, seamBp - offV);
+        }
     }
+    if (!rec.escape) {
+        copy_bulk(spS, spU, spV);
+    } else if constexpr (DEPTH == 16) {
+        // raw 16-bit samples, MSB first: two little-endian samples per PCM word, swapped into place by a rotate
+        const uint32_t *pw = (const uint32_t *)pk;  // 16-byte aligned packet (checked by the C entry point)
+        copy_span(spR, offRaw, [&](uint32_t i) {
+            const uint32_t x = pw[i];
+            return (x << 16) | (x >> 16);
+        });
+    } else if constexpr (DEPTH == 32) {
+        // raw 32-bit samples, MSB first: the word IS the little-endian sample
+        const uint32_t *pw = (const uint32_t *)pk;
+        copy_span(spR, offRaw, [&](uint32_t i) { return pw[i]; });
+    } else if constexpr (DEPTH == 24) {
+        // raw 24-bit samples, MSB first: four samples (PCM bytes B0..B11 in three dwords) make three words
+        // B2 B1 B0 B5 | B4 B3 B8 B7 | B6 B11 B10 B9.  A lane's five source words i .. i + 4 lie in three such triples:
+        // nine dwords loaded unconditionally (two 16-byte loads + one), all nine words formed, five picked by i mod 3.
+        const uint32_t *pw = (const uint32_t *)pk;
+        const uint32_t ndw = (N * CH * 3 + 3) / 4;  // dwords that hold samples (the tail of the last one is padding)
+        const uint32_t fb = first_bit(spR, offRaw), i0 = fb >> 5, sh = fb & 31;
+        for (uint32_t w = spR.w0 + 4 * threadIdx.x; w < spR.w1; w += 4 * blockDim.x) {
+            const uint32_t i = i0 + (w - spR.w0);
+            const uint32_t g = i / 3, r = i - 3 * g, base = 3 * g;
+            uint32_t d[9];
+            if (base + 9 <= ndw) {
+                const U4 x = *(const U4 *)(pw + base), y = *(const U4 *)(pw + base + 4);
+                d[0] = x.x, d[1] = x.y, d[2] = x.z, d[3] = x.w, d[4] = y.x, d[5] = y.y, d[6] = y.z, d[7] = y.w;
+                d[8] = pw[base + 8];
+            } else {
+                // the end of the samples: dwords past it feed only words (or low bits of the fifth word) nobody uses
+#pragma unroll
+                for (uint32_t q = 0; q < 9; q++) d[q] = pw[min(base + q, ndw - 1)];
+            }
+            uint32_t W[9];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const uint32_t d0 = d[3 * t], d1 = d[3 * t + 1], d2 = d[3 * t + 2];
+                W[3 * t] = (d0 << 8) | ((d1 >> 8) & 0xffu);
+                W[3 * t + 1] = (d1 << 24) | ((d0 >> 24) << 16) | ((d2 & 0xffu) << 8) | (d1 >> 24);
+                W[3 * t + 2] = (((d1 >> 16) & 0xffu) << 24) | ((d2 >> 24) << 16) | (((d2 >> 16) & 0xffu) << 8) | ((d2 >> 8) & 0xffu);
+            }
+            uint32_t a[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) a[q] = r == 0 ? W[q] : (r == 1 ? W[q + 1] : W[q + 2]);
+            store4(a, sh, w);
+        }
+    } else {
+        // raw 20-bit samples, MSB first: eight samples (24 PCM bytes, six dwords) make five words.  A lane's five source
+        // words lie in two such periods: twelve dwords, sixteen samples, ten words, five picked by i mod 5.
+        const uint32_t *pw = (const uint32_t *)pk;
+        const uint32_t ndw = (N * CH * 3 + 3) / 4;
+        const uint32_t fb = first_bit(spR, offRaw), i0 = fb >> 5, sh = fb & 31;
+        for (uint32_t w = spR.w0 + 4 * threadIdx.x; w < spR.w1; w += 4 * blockDim.x) {
+            const uint32_t i = i0 + (w - spR.w0);
+            const uint32_t g = i / 5, r = i - 5 * g, base = 6 * g;
+            uint32_t d[12];
+            if (base + 12 <= ndw) {
+                const U4 x = *(const U4 *)(pw + base), y = *(const U4 *)(pw + base + 4), z = *(const U4 *)(pw + base + 8);
+                d[0] = x.x, d[1] = x.y, d[2] = x.z, d[3] = x.w, d[4] = y.x, d[5] = y.y, d[6] = y.z, d[7] = y.w;
+                d[8] = z.x, d[9] = z.y, d[10] = z.z, d[11] = z.w;
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 12; q++) d[q] = pw[min(base + q, ndw - 1)];
+            }
+            uint32_t W[10];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                uint32_t sm[8];  // the 20-bit fields of eight samples (top 20 bits of each 3-byte little-endian sample)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t d0 = d[6 * t + 3 * h], d1 = d[6 * t + 3 * h + 1], d2 = d[6 * t + 3 * h + 2];
+                    sm[4 * h] = (d0 & 0xffffffu) >> 4;
+                    sm[4 * h + 1] = (((d0 >> 24) | (d1 << 8)) & 0xffffffu) >> 4;
+                    sm[4 * h + 2] = (((d1 >> 16) | (d2 << 16)) & 0xffffffu) >> 4;
+                    sm[4 * h + 3] = d2 >> 12;
+                }
+                W[5 * t] = (sm[0] << 12) | (sm[1] >> 8);
+                W[5 * t + 1] = (sm[1] << 24) | (sm[2] << 4) | (sm[3] >> 16);
+                W[5 * t + 2] = (sm[3] << 16) | (sm[4] >> 4);
+                W[5 * t + 3] = (sm[4] << 28) | (sm[5] << 8) | (sm[6] >> 12);
+                W[5 * t + 4] = (sm[6] << 20) | sm[7];
+            }
+            uint32_t a[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                a[q] = r == 0 ? W[q] : (r == 1 ? W[q + 1] : (r == 2 ? W[q + 2] : (r == 3 ? W[q + 3] : W[q + 4])));
+            store4(a, sh, w);
+        }
+    }
+
+    if (seamWave) {
+        if (lane < nSeam) {
+            uint32_t v = seam_rest(seamBp);
+            if (!rec.escape) {
+                v |= combine_pair(seamU, lenU, seamBp - offU);
+                if constexpr (CH == 2) v |= combine_pair(seamV, lenV, seamBp - offV);
+            }
+            seam_store(seamAw, v);
+        }
+        for (uint32_t k = lane + 64; k < nSeam; k += 64) {  // more than 64 seam words: tiny packets of odd shapes only
+            const uint32_t aw = seam_word(k);
+            const int64_t bp = (int64_t)aw * 32 - (int64_t)mis * 8;
+            uint32_t v = seam_rest(bp);
+            if (!rec.escape) {
+                v |= combine_pair(fetch_pair(wU, lenU, bp - offU), lenU, bp - offU);
+                if constexpr (CH == 2) v |= combine_pair(fetch_pair(wV, lenV, bp - offV), lenV, bp - offV);
+            }
+            seam_store(aw, v);
+        }
+    }
+    }  // packets of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -721,14 +901,20 @@ static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, con
     hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const uint32_t *)packetBytes, (uint64_t *)pa.offsets,
                        numPackets);
     if (ev) (void)hipEventRecord(ev[kStagePack], st);
-    // 256 threads per packet.  Measured at 10 000 16-bit / 24-bit packets and at 125 000: 64 threads 0.127 / 0.43 / 1.32 ms,
-    // 128: 0.102 / 0.28 / 0.99, 256: 0.100 / 0.234 / 1.06; 512 (which needs __launch_bounds__(512) and its tighter register
-    // budget) 0.16 / 0.28 / 1.83 — the copy is bound by the latency of a workgroup's dependent loads, not by bandwidth.
-    constexpr uint32_t tpb = 256;
+    // One workgroup of 128 threads per packet (ALAC_HIP_PACK_TPB / ALAC_HIP_PACK_WGS override; with fewer workgroups than
+    // packets each walks several).  Measured at 10 000 16-bit packets / 125 000 (tools/dispatch_rate_microbench.hip for the
+    // plain-copy floor): 64 threads 0.064 / 0.66 ms, 128: 0.064 / 0.66, 256: 0.067 / 0.74; 2048 persistent workgroups
+    // 0.079 / 0.93; a plain 6.8 KB-per-workgroup copy of the same bytes 0.017 / 0.29.  Workgroup dispatch is not the limit
+    // (125 000 empty workgroups launch in 0.03 ms).  What round 2 removed: a workgroup-wide barrier behind a header built by
+    // one lane, a second pass over all words for the seams, up to four dependent loads in front of / behind every span, and
+    // — the big one for 20- / 24-bit — sample-by-sample loops with a dependent load per step (an escape packet took 180 us).
+    static const uint32_t tpb = getenv("ALAC_HIP_PACK_TPB") ? (uint32_t)atoi(getenv("ALAC_HIP_PACK_TPB")) : 128u;
+    static const uint32_t wgs = getenv("ALAC_HIP_PACK_WGS") ? (uint32_t)atoi(getenv("ALAC_HIP_PACK_WGS")) : (1u << 20);
+    const uint32_t grid = numPackets < wgs ? numPackets : wgs;
     if (channels == 2)
-        hipLaunchKernelGGL((k_pack<DEPTH, 2>), dim3(numPackets), dim3(tpb), 0, st, pa);
+        hipLaunchKernelGGL((k_pack<DEPTH, 2>), dim3(grid), dim3(tpb), 0, st, pa, numPackets);
     else
-        hipLaunchKernelGGL((k_pack<DEPTH, 1>), dim3(numPackets), dim3(tpb), 0, st, pa);
+        hipLaunchKernelGGL((k_pack<DEPTH, 1>), dim3(grid), dim3(tpb), 0, st, pa, numPackets);
     if (ev) (void)hipEventRecord(ev[kNumStages], st);
 }
 
