@@ -365,33 +365,36 @@ __global__ __launch_bounds__(64) void k_encode_mono(EncodeArgs A)
 // exclusive scan of packet sizes (uint32 -> uint64 offsets, offsets[n] = total)
 // ------------------------------------------------------------------------------------------------
 
+// Workgroup b owns elements [1024 b, 1024 b + 1024).  It first adds up everything in front of its block on its own —
+// thread t sums sizes[t], sizes[t + 1024], ... (coalesced, independent loads; the sizes sit in L2) — instead of waiting
+// for its predecessors: no scratch memory, no inter-workgroup hand-off, one launch.  The redundant reads are b * 4 KB per
+// workgroup (125 000 packets: 30 MB in all); the single workgroup this replaces took 0.17 ms there.
 __global__ __launch_bounds__(1024) void k_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n)
 {
     __shared__ uint64_t waveSum[16];
-    __shared__ uint64_t carry;
+    __shared__ uint64_t wavePre[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + tid;
-        const uint64_t v = i < n ? sizes[i] : 0;
-        uint64_t incl = v;
+    const uint32_t base = blockIdx.x * 1024u;
+    uint64_t before = 0;
+    for (uint32_t i = tid; i < base; i += 1024) before += sizes[i];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t t = __shfl_up(incl, d);
-            if ((int)lane >= d) incl += t;
-        }
-        if (lane == 63) waveSum[wave] = incl;
-        __syncthreads();
-        uint64_t wpre = 0;
-        for (uint32_t w = 0; w < wave; w++) wpre += waveSum[w];
-        const uint64_t c = carry;
-        if (i < n) offsets[i] = c + wpre + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry = c + wpre + incl;
-        __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+    const uint32_t i = base + tid;
+    const uint64_t v = i < n ? sizes[i] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += t;
     }
-    if (tid == 0) offsets[n] = carry;
+    if (lane == 63) waveSum[wave] = incl;
+    if (lane == 0) wavePre[wave] = before;
+    __syncthreads();
+    uint64_t pre = 0;
+    for (uint32_t w = 0; w < 16; w++) pre += wavePre[w] + (w < wave ? waveSum[w] : 0);
+    if (i < n) offsets[i] = pre + incl - v;
+    if (i == n - 1) offsets[n] = pre + incl;
+    if (n == 0 && i == 0) offsets[0] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -898,7 +901,7 @@ static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, con
                                    hipStream_t st, hipEvent_t *ev, bool recordScan = true)
 {
     if (ev && recordScan) (void)hipEventRecord(ev[kStageScan], st);
-    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, (const uint32_t *)packetBytes, (uint64_t *)pa.offsets,
+    hipLaunchKernelGGL(k_scan_sizes, dim3(numPackets / 1024 + 1), dim3(1024), 0, st, (const uint32_t *)packetBytes, (uint64_t *)pa.offsets,
                        numPackets);
     if (ev) (void)hipEventRecord(ev[kStagePack], st);
     // One workgroup of 128 threads per packet (ALAC_HIP_PACK_TPB / ALAC_HIP_PACK_WGS override; with fewer workgroups than
@@ -920,7 +923,7 @@ static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, con
 
 void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, st, sizes, offsets, n);
+    hipLaunchKernelGGL(k_scan_sizes, dim3(n / 1024 + 1), dim3(1024), 0, st, sizes, offsets, n);
 }
 
 void launch_scan_pack(uint32_t depth, uint32_t channels, uint32_t *packetBytes, const PackArgs &pa, uint32_t numPackets,
