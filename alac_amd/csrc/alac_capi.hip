@@ -96,7 +96,16 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     EncLayout L;
     // escape size bounds what a compressed element may use (codec/ALACEncoder.cu:459,:538)
     const uint64_t escapeBits = (uint64_t)f->frame_size * f->bit_depth * f->num_channels + 32 + 16;
-    L.wcap = (uint32_t)(((escapeBits + 31) / 32 + 4 + 3) & ~3ull);  // a multiple of 4 words: 16-byte aligned channel slots
+    // + 44 words: the written coder guards its slot 34 words before the end (alac_golomb.hpp, golf_open), and a channel that
+    // gets there must by itself be longer than the escape size; a multiple of 4 words: 16-byte aligned channel slots.
+    // The slot stride also decides how the coder's scattered stores (one word per lane and symbol in the latency regime,
+    // ~10^11 L2 write requests per second) fall onto the L2 channels: measured at 10 000 packets, the final launch takes
+    // 0.746 ms with 16 576-byte slots (16-bit stereo, this formula), 0.78-0.80 ms 32 or 256 bytes further, and 0.96 ms with
+    // the 24 768 bytes the formula gives 24-bit stereo against 0.76 ms 16 bytes further — hence the extra group there.
+    // ALAC_HIP_WCAP_PAD (words) adds to it for experiments.
+    L.wcap = (uint32_t)(((escapeBits + 31) / 32 + 44 + 3) & ~3ull);
+    if (f->bit_depth == 24) L.wcap += 4;
+    if (const char *e = getenv("ALAC_HIP_WCAP_PAD")) L.wcap += (uint32_t)atoi(e) & ~3u;
     const uint64_t lanes = align_up((uint64_t)numSegments * f->num_channels, 64);
     L.predStride = lanes;
     uint64_t off = 0;

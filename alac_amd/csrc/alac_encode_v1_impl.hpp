@@ -931,11 +931,11 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
     const uint64_t stride = A.chainsPad;
     GolF g;
     golf_reset(g);
-    g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
-    g.wleft = A.wcap - 1;
+    uint32_t *slot = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
+    golf_open(g, slot, A.wcap);
     golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), NoWait(), A.idleFast != 0);
     golf_flush<true>(g);
-    if (active) rec->c[c].bits = g.bits;
+    if (active) rec->c[c].bits = golf_written_bits(g, slot);
 }
 
 // ---- k_final_fused: the final predictor pass and the final entropy coder in ONE launch.  Workgroups
@@ -996,8 +996,8 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         const uint64_t stride = A.chainsPad;
         GolF g;
         golf_reset(g);
-        g.wp = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
-        g.wleft = A.wcap - 1;
+        uint32_t *slot = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
+        golf_open(g, slot, A.wcap);
         RowWait wait;
         wait.producers(A.flagsF, L * w, L, nLms);
         wait.avail = 0;
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         wait.ho = A.ho;
         golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
         golf_flush<true>(g);
-        if (active) rec->c[c].bits = g.bits;
+        if (active) rec->c[c].bits = golf_written_bits(g, slot);
     }
 }
 
@@ -1197,12 +1197,12 @@ __global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits,
     const uint32_t n = active ? N : 0;
     GolF g;
     golf_reset(g);
-    g.wp = A.bitWords + (active ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + (lane & 1)) * A.wcap;
-    g.wleft = A.wcap - 1;
+    uint32_t *slot = A.bitWords + (active ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + (lane & 1)) * A.wcap;
+    golf_open(g, slot, A.wcap);
     golf_stream<true, true, NoWait, LAZY>(g, n, wave_max(n), chanBits, recip, one_plane(A.resC, A.colsPad, col), NoWait(),
                                           A.idleFast != 0);
     golf_flush<true, LAZY>(g);
-    if (active) rec->c[c].bits = g.bits;
+    if (active) rec->c[c].bits = golf_written_bits<LAZY>(g, slot);
 }
 
 // packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)

@@ -28,6 +28,7 @@ struct GolF {
     uint64_t acc;      // the most recent bits, right aligned; the low `nacc` of them are not yet a full word
     uint32_t nacc, wleft;
     uint32_t *wp;      // where the word being assembled goes
+    uint32_t *wlim;    // !LAZY: wp is pulled back to this once per 16-symbol block (golf_stream) — the capacity guard
     // LAZY form only: completed words not yet stored — the last qn of (q0, q1, q2, q3), oldest first — so that they leave
     // four at a time in one 16-byte store (wp stays 16-byte aligned: slots are wcap words apart, wcap a multiple of 4)
     uint32_t q0, q1, q2, q3, qn;
@@ -44,6 +45,7 @@ __device__ __forceinline__ void golf_reset(GolF &g)
     g.nacc = 0;
     g.wleft = 0;
     g.wp = nullptr;
+    g.wlim = nullptr;
     g.q0 = g.q1 = g.q2 = g.q3 = g.qn = 0;
 }
 
@@ -54,7 +56,8 @@ __device__ __forceinline__ void golf_reset(GolF &g)
 template <bool WRITE, bool LAZY = false>
 __device__ __forceinline__ void golf_put(GolF &g, uint32_t value, uint32_t nbits)
 {
-    g.bits += nbits;
+    // WRITE: the bit count is where the word pointer ended up (golf_written_bits), not an add per symbol
+    if constexpr (!WRITE) g.bits += nbits;
     if constexpr (WRITE) {
         g.acc = (g.acc << nbits) | (uint64_t)value;  // callers hand in values already confined to nbits
         g.nacc += nbits;
@@ -81,13 +84,30 @@ __device__ __forceinline__ void golf_put(GolF &g, uint32_t value, uint32_t nbits
                 g.qn = 0;
             }
         } else {
+            // no capacity test per symbol: a put completes at most one word, a symbol makes at most two puts, and
+            // golf_stream pulls wp back to wlim (34 words before the slot's end) once per 16 symbols
             *g.wp = word;
-            const uint32_t adv = min(g.nacc >> 5, g.wleft);  // capacity reached: stay (the packet escapes anyway)
-            g.wleft -= adv;
-            g.wp += adv;
+            g.wp += g.nacc >> 5;
         }
         g.nacc &= 31u;
     }
+}
+
+// Start a written stream in its slot of `wcap` words.  A stream that reaches the guard (wcap - 34 words, resp. the last
+// 16-byte group in the LAZY form) keeps overwriting the slot's tail; enc_layout sizes wcap so that such a stream is
+// longer than the escape size by itself: the packet is sent uncompressed and nobody reads the slot.
+__device__ __forceinline__ void golf_open(GolF &g, uint32_t *slot, uint32_t wcap)
+{
+    g.wp = slot;
+    g.wlim = slot + (wcap - 34);
+    g.wleft = wcap - 1;
+}
+
+// bits of a written stream (exact unless the guard was reached, and then at least 32 (wcap - 34))
+template <bool LAZY = false>
+__device__ __forceinline__ uint32_t golf_written_bits(const GolF &g, const uint32_t *slot)
+{
+    return 32u * ((uint32_t)(g.wp - slot) + (LAZY ? g.qn : 0u)) + g.nacc;
 }
 
 // the bits left over after the last full word (golf_put stores before it advances)
@@ -299,12 +319,17 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
     // but the last blocks of a wave) then fits the instruction cache — 48 unrolled symbols are ~36 KB, and with
     // the checked variant in the same loop the body would be twice that (a 3 x 32-symbol body, 147 KB, was measured
     // 3.5 x slower: the 64 KB instruction cache is a hard limit for these kernels).
+    auto guard = [&]() {
+        if constexpr (WRITE && !LAZY) g.wp = g.wp < g.wlim ? g.wp : g.wlim;
+    };
     auto codeFast = [&](const int32_t (&buf)[B]) {
+        guard();
 #pragma unroll
         for (int s = 0; s < B; s++) golf_sym<WRITE, false, ZZ, LAZY>(g, buf[s], true, bitSize, recip);
     };
     auto codeChecked = [&](const int32_t (&buf)[B], uint32_t jb) {
         if (jb >= nMaxWave) return;
+        guard();
 #pragma unroll
         for (int s = 0; s < B; s++) golf_sym<WRITE, true, ZZ, LAZY>(g, buf[s], jb + s < n, bitSize, recip);
     };
