@@ -58,9 +58,23 @@
     X(44, "v_mad_i32_i24 %0, %0, %4, %0\n s_add_u32 s20, s20, 3") \
     X(45, "ds_bpermute_b32 %0, %0, %0\n s_waitcnt lgkmcnt(0)") \
     X(46, "v_readlane_b32 s20, %0, 3\n v_add_u32 %0, s20, %0") \
-    X(47, "v_sad_u32 %0, %0, %4, %0")
+    X(47, "v_sad_u32 %0, %0, %4, %0") \
+    X(48, "v_lshrrev_b32 %0, 1, %0") \
+    X(49, "v_lshrrev_b32 %0, %4, %0") \
+    X(50, "v_ashrrev_i32 %0, %4, %0") \
+    X(51, "v_lshlrev_b32 %0, %4, %0") \
+    X(52, "v_or_b32 %0, %0, %4") \
+    X(53, "v_not_b32 %0, %0") \
+    X(54, "v_subrev_u32 %0, %0, %4") \
+    X(55, "v_bfe_u32 %0, %0, 3, 9") \
+    X(56, "v_cmp_gt_i32 vcc, %0, %4\n v_addc_co_u32 %0, vcc, 0, %0, vcc") \
+    X(57, "v_cmp_gt_i32 vcc, %0, %4\n v_subb_co_u32 %0, vcc, %0, %4, vcc") \
+    X(58, "v_perm_b32 %0, %0, %4, %0") \
+    X(59, "v_xad_u32 %0, %0, %4, %0") \
+    X(60, "v_lshl_or_b32 %0, %0, 1, %4") \
+    X(61, "v_mul_i32_i24 %0, %0, %4\n v_add_u32 %1, %1, %4")
 
-static const int kInstr[] = {1,1,1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,1,1, 4,4,2,2,3,4,4,4,4,1, 1,1,2,2,2,2,2,1};
+static const int kInstr[] = {1,1,1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,1,1, 4,4,2,2,3,4,4,4,4,1, 1,1,2,2,2,2,2,1, 1,1,1,1,1,1,1,1,2,2, 1,1,1,2};
 
 template <int T>
 __global__ void k(uint64_t *out, int iters, int seed)
@@ -116,18 +130,21 @@ void run(uint64_t *d)
 template <int T>
 void run_all(uint64_t *d)
 {
-    if constexpr (T < 48) {
+    if constexpr (T < 62) {
         run<T>(d);
         run_all<T + 1>(d);
     }
 }
 
-int main()
+int main(int argc, char **)
 {
     uint64_t *d;
     hipMalloc(&d, 8192);
     hipMemset(d, 0, 8192);
     printf("SIMD cycles (at 2.4 GHz) per wave-instruction with 1 / 2 / 4 / 8 waves per SIMD\n");
-    run_all<0>(d);
+    if (argc > 1)
+        run_all<48>(d);  // only the opcodes added in the second batch
+    else
+        run_all<0>(d);
     return 0;
 }
