@@ -72,6 +72,8 @@ SIGNATURES = {
     "alac_synth_frame": (None, [_u64, _u32, _u32, _u32, _vp]),
     "alac_synth_pcm": (None, [_u64, _u32, _u32, _u32, _u32, _vp]),
     "alac_hip_synth_pcm": (_i32, [_vp, _u64, _u32, C.POINTER(Format), _vp]),
+    "alac_hip_shard_range": (_i32, [_u64, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
+    "alac_hip_shard_offsets": (_i32, [_vp, _u32, _vp]),
 }
 
 _lib = None
@@ -95,6 +97,24 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def shard_range(num_units, world, rank):
+    """(first, count) of the units rank `rank` of `world` encodes (alac_hip_shard_range); raises on bad arguments"""
+    first, count = _u64(), _u64()
+    if load_library().alac_hip_shard_range(num_units, world, rank, C.byref(first), C.byref(count)) != 0:
+        raise ValueError(f"bad shard arguments: world {world}, rank {rank}")
+    return first.value, count.value
+
+
+def shard_offsets(shard_bytes):
+    """byte offsets of the shards in the re-assembled stream, [world + 1] (alac_hip_shard_offsets)"""
+    n = len(shard_bytes)
+    src = (_u64 * n)(*[int(x) for x in shard_bytes])
+    dst = (_u64 * (n + 1))()
+    if load_library().alac_hip_shard_offsets(src, n, dst) != 0:
+        raise ValueError("bad shard sizes")
+    return list(dst)
 
 
 def synth_pcm(first_frame, num_frames, fmt):

@@ -73,8 +73,8 @@ class Reassembler:
         mine = int(lens_h[self.rank].item())
         if mine > shard.numel():
             raise ValueError("shard buffer shorter than its declared length")
-        offsets_h = torch.zeros(self.world + 1, dtype=torch.int64)
-        offsets_h[1:] = torch.cumsum(lens_h, 0)
+        from .capi import shard_offsets  # the C-ABI's prefix sums (alac_hip_shard_offsets)
+        offsets_h = torch.tensor(shard_offsets(lens_h.tolist()), dtype=torch.int64)
         total = int(offsets_h[-1].item())
         if self.stream is None or self.stream.numel() < total:
             self.stream = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)

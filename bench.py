@@ -182,7 +182,8 @@ def main():
 
     fmt = alac_amd.make_format(4096, args.bit_depth, 2, 44100)
     B = args.packets if args.packets > 0 else (10000 if world == 1 else 125000)
-    first_frame = rank * B
+    first_frame, mine = alac_amd.shard_range(world * B, world, rank)  # weak scaling: B packets on every rank
+    assert mine == B
     ctx = alac_amd.Context(local_rank)
 
     # synthetic input, generated ON THE DEVICE (alac_hip_synth_pcm: same source and bytes as the host generator the

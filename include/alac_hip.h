@@ -215,6 +215,15 @@ void alac_synth_pcm(uint64_t first_frame, uint32_t num_frames, uint32_t frame_si
 int32_t alac_hip_synth_pcm(alac_hip_ctx *ctx, uint64_t first_frame, uint32_t num_frames,
                            const alac_hip_format *fmt, uint8_t *d_out);
 
+/* ---- sharding across GPUs, host only ------------------------------------------------------
+ * One process per GPU encodes a contiguous range of the independent units (segments / packets); the shards are byte
+ * aligned (codec/ALACEncoder.cu:1039), so the stream is their concatenation in rank order.
+ * alac_hip_shard_range: rank `rank` of `world` takes units [*first, *first + *count); the ranges tile [0, num_units).
+ * alac_hip_shard_offsets: offsets[r] = byte position of rank r's shard in the re-assembled stream, offsets[world] = its
+ * length (the exclusive prefix sum of the all-gathered shard sizes).  Both return 0 or kALAC_ParamError. */
+int32_t alac_hip_shard_range(uint64_t num_units, uint32_t world, uint32_t rank, uint64_t *first, uint64_t *count);
+int32_t alac_hip_shard_offsets(const uint64_t *shard_bytes, uint32_t world, uint64_t *offsets);
+
 #ifdef __cplusplus
 }
 #endif

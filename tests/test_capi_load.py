@@ -86,3 +86,21 @@ def test_reference_stage_prototypes_are_exported():
     for name in ("init_coefs", "copy_coefs", "pc_block", "unpc_block", "set_ag_params", "set_standard_ag_params",
                  "dyn_comp", "dyn_decomp"):
         assert getattr(lib, name) is not None
+
+
+def test_shard_arithmetic_is_host_only_and_tiles_the_units():
+    """contiguous ranges per rank that tile [0, S), prefix-sum offsets of the shard bytes"""
+    for units, world in [(1000000 // 8 * 8, 8), (10, 3), (5, 8), (0, 2), (125000 * 8, 8), (7, 1)]:
+        at = 0
+        for r in range(world):
+            first, count = alac_amd.shard_range(units, world, r)
+            assert first == at and count in (units // world, units // world + 1)
+            at += count
+        assert at == units
+    with pytest.raises(ValueError):
+        alac_amd.shard_range(10, 0, 0)
+    with pytest.raises(ValueError):
+        alac_amd.shard_range(10, 4, 4)
+    assert alac_amd.shard_offsets([5, 0, 7]) == [0, 5, 5, 12]
+    with pytest.raises(ValueError):
+        alac_amd.shard_offsets([2 ** 64 - 1, 2])
