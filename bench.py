@@ -372,6 +372,19 @@ def main():
                              "source": "profiles/instruction_mix.json (rocprofv3 --pmc SQ_INSTS_*, same command)"}
             except Exception as e:
                 issue = {"error": repr(e)}
+        elif os.path.exists(ipath) and B == 125000 and args.bit_depth == 16 and thru:
+            # throughput regime: the class launches of the final pass overlap on two streams, so the honest figure is the
+            # whole step: every kernel's wave-instructions (same PMC pass) over the step's GPU time
+            try:
+                with open(ipath) as f:
+                    tot = json.load(f)["throughput_125000"]["wave_instructions_per_step"]
+                ach = tot / (gpu_ms * 1e-3) / 1e9
+                issue = {"bound": "valu-issue", "scope": "whole step (all kernels)", "achieved": round(ach, 1),
+                         "peak": round(ISSUE_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                         "frac": round(ach / ISSUE_PEAK_GINST, 3), "wave_instructions_per_step": int(tot),
+                         "source": "profiles/instruction_mix.json throughput_125000 (rocprofv3 --pmc SQ_INSTS_*, same command)"}
+            except Exception as e:
+                issue = {"error": repr(e)}
         cfg_name = "configs[1]" if (world == 1 and B == 10000) else ("configs[3] shard shape" if B == 125000 else "custom batch")
         out = {
             "metric": baseline_metric(),
