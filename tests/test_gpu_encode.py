@@ -167,3 +167,50 @@ def test_throughput_regime_with_chained_segments(gpu_ctx, oracle):
             pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * fmt.bytes_per_frame], int(ns[p]))
             assert sizes[p] == len(pk), (s, p)
             assert np.array_equal(stream[offs[p]:offs[p + 1]], pk), (s, p)
+
+
+@pytest.mark.parametrize("depth", [16, 20, 24, 32])
+@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("frame", [4096, 333])
+def test_packer_spans_and_seams_every_depth(gpu_ctx, oracle, depth, channels, frame):
+    """The packer's fast paths (k_pack): escape payloads read with wide loads and picked by i mod 3 (24-bit) / i mod 5
+    (20-bit), shift-off bytes, the words either side of every span, ragged ends — packets of full-scale noise (escape)
+    and of a quiet tone (compressed), every length class, at every byte alignment the running offset produces."""
+    import torch
+    fmt = alac_amd.make_format(frame, depth, channels)
+    lengths = [frame, frame - 1, frame - 2, frame - 3, max(frame // 3, 1), 37, 6, 5, 4, 3, 2, 1]
+    ns = np.array([n for n in lengths for _ in range(2)], np.int32)  # each length once as noise, once as tone
+    n = len(ns)
+    rng = np.random.default_rng(depth * 100 + channels * 10 + (frame & 7))
+    bpf = fmt.bytes_per_frame
+    pcm = np.zeros(n * fmt.packet_bytes, np.uint8)
+    top = 1 << (depth - 1)
+    for p in range(n):
+        N = int(ns[p])
+        if p % 2 == 0:
+            a = rng.integers(-top, top, (N, channels), dtype=np.int64)  # incompressible: the escape path
+        else:
+            t = np.arange(N)[:, None]
+            a = np.round(top / 64 * np.sin(2 * np.pi * 440.0 * t / 44100.0 + np.arange(channels))).astype(np.int64)
+            a += rng.integers(-2, 3, a.shape)
+        if depth == 16:
+            b = a.astype("<i2").view(np.uint8).reshape(-1)
+        elif depth == 32:
+            b = a.astype("<i4").view(np.uint8).reshape(-1)
+        else:
+            if depth == 20:
+                a = a << 4
+            b = (a & 0xffffff).astype("<u4").view(np.uint8).reshape(-1, 4)[:, :3].reshape(-1).copy()
+        pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + N * bpf] = b
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, num_samples=torch.from_numpy(ns).cuda())
+    enc = oracle.encoder(frame, depth, channels)
+    off, escapes = 0, 0
+    for p in range(n):
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + int(ns[p]) * bpf], int(ns[p]))
+        escapes += enc.last_info()["escape"]
+        assert sizes[p] == len(pk), (p, int(ns[p]))
+        assert np.array_equal(stream[off:off + len(pk)], pk), (p, int(ns[p]))
+        off += len(pk)
+    assert off == len(stream)
+    assert escapes >= 4  # the noise packets of useful length really took the uncompressed path
