@@ -262,8 +262,8 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets, uint64_t str
     off = align_up(off + (uint64_t)numPackets * L.maxElems * sizeof(DecRec), 256);
     L.resid = off;
     off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
-    L.prog = off;
-    off = align_up(off + (uint64_t)numPackets * 8, 256);
+    L.prog = off;  // progress words of the fused launch / chain list + two counters of the separate launches
+    off = align_up(off + (uint64_t)numPackets * 8 + 8, 256);
     L.elemBit = off;
     off = align_up(off + (uint64_t)numPackets * 4, 256);
     L.mismatch = off;

@@ -723,6 +723,143 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
 
 __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_body<false>(V, blockIdx.x); }
 
+// ---- separate launches (large batches): ONE lane per chain, chains sorted by tap count -------------------------------
+// Where every kernel fills the machine by itself the cost of the predictor is wave-instructions per chain step, and
+// the two-lane mapping above spends 58 per 32 chains.  Here a lane holds all T taps of its chain (T = 4 or 8 = the
+// chain's own tap count, so there are no dead taps, no cross-lane exchange and the weights are compile-time constants)
+// and a wave walks 64 chains.  k_dec_classify sorts the chains the fast path accepts by tap count into ONE list filled
+// from both ends (4-tap chains from the front, 8-tap chains from the back; it lives in the progress words of the fused
+// launch, which this regime does not use; the two counters sit behind them).
+__global__ __launch_bounds__(256) void k_dec_classify(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const uint32_t total = A.numPackets * A.numChannels;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false, wide = false;
+    if (gid < total) {
+        const uint32_t p = gid / A.numChannels, ch = gid % A.numChannels;
+        const DecRec *rec = A.recs + p;
+        ok = unpc_fast_ok(A, rec, ch);
+        wide = ok && rec->c[ch].num == 8;
+    }
+    uint32_t *list = V.prog, *cnt = V.prog + 2 * (uint64_t)A.numPackets;
+    const uint64_t m4 = __ballot(ok && !wide), m8 = __ballot(wide);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t below = (1ull << lane) - 1;
+    uint32_t b4 = 0, b8 = 0;
+    if (lane == 0) {
+        if (m4) b4 = atomicAdd(cnt, (uint32_t)__popcll(m4));
+        if (m8) b8 = atomicAdd(cnt + 1, (uint32_t)__popcll(m8));
+    }
+    b4 = (uint32_t)__shfl((int)b4, 0);
+    b8 = (uint32_t)__shfl((int)b8, 0);
+    if (ok && !wide) list[b4 + (uint32_t)__popcll(m4 & below)] = gid;
+    if (wide) list[total - 1 - (b8 + (uint32_t)__popcll(m8 & below))] = gid;
+}
+
+// one unpc step of a lane that holds all T taps: returns out[j]; updates a[], the window w[] and tp
+template <int T>
+__device__ __forceinline__ int32_t lms_step_dec_wide(int32_t (&a)[T], int32_t (&w)[T], int32_t &tp, int32_t del, uint32_t chanbits)
+{
+    int32_t b[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) b[i] = tp - w[i];
+    int32_t s = 255;  // -((256 - s) >> 9) == (s + 255) >> 9
+#pragma unroll
+    for (int i = 0; i < T; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;
+    const int32_t out = __builtin_amdgcn_sbfe(del + tp - (s >> kDenShift), 0, chanbits);
+    // coefficient update, driven by del: the threshold form of the walk (alac_lms.hpp), weights T - i
+    const int32_t nd = -del;
+    const int32_t adel = max(del, nd);
+    const int32_t nsg = sign3(nd);
+    const int32_t rc = (del >> 31) & ((1 << kDenShift) - 1);
+    int32_t sb[T];
+    uint32_t t[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        sb[i] = sign3(b[i]);
+        t[i] = (uint32_t)(__mul24(sb[i], b[i]) + rc) >> kDenShift;
+    }
+    int32_t S[T];
+    S[T - 1] = 0;
+#pragma unroll
+    for (int i = T - 1; i > 0; i--) S[i - 1] = (int32_t)__umul24(t[i], (uint32_t)(T - i)) + S[i];
+#pragma unroll
+    for (int i = 0; i < T; i++) a[i] = __mul24(adel > S[i] ? nsg : 0, sb[i]) + a[i];
+    tp = w[T - 1];
+#pragma unroll
+    for (int i = T - 1; i > 0; i--) w[i] = w[i - 1];
+    w[0] = out;
+    return out;
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
+{
+    const DecodeArgs &A = V.d;
+    const uint32_t total = A.numPackets * A.numChannels;
+    const uint32_t count = V.prog[2 * (uint64_t)A.numPackets + (T == 8 ? 1 : 0)];
+    if (blockIdx.x * 64u >= count) return;
+    const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    const bool active = idx < count;
+    const uint32_t chain = active ? (T == 8 ? V.prog[total - 1 - idx] : V.prog[idx]) : 0;
+    const uint32_t p = chain / A.numChannels, ch = chain % A.numChannels;
+    const DecRec *rec = A.recs + p;
+    const uint32_t n = active ? rec->numSamples : 0;
+    const uint32_t chanbits = A.bitDepth - (active ? rec->bytesShifted : 0) * 8 + ((active ? rec->elementChannels : 1) == 2 ? 1 : 0);
+    int32_t *row = V.plane + (uint64_t)chain * A.frameSize;
+
+    // ---- head: the first 16 samples lane-serially (warm-up positions + the first regular steps) ----
+    int32_t d16[16], o16[16], a8[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int4 t = active ? ((const int4 *)row)[q] : make_int4(0, 0, 0, 0);
+        d16[4 * q] = t.x;
+        d16[4 * q + 1] = t.y;
+        d16[4 * q + 2] = t.z;
+        d16[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) a8[k] = (active && k < T) ? (int32_t)rec->c[ch].coefs[k] : 0;
+    unpc_head16<T>(d16, o16, a8, 32 - chanbits);
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) ((int4 *)row)[q] = make_int4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]);
+    }
+    int32_t a[T], w[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        a[i] = a8[i];
+        w[i] = o16[15 - i];  // out[j - 1 - i] at j = 16
+    }
+    int32_t tp = o16[15 - T];  // out[j - T - 1]
+
+    // ---- 8-step blocks; the residuals of block i + 1 are loaded while block i computes ----
+    const uint32_t nMax = wave_max_u32(n);
+    auto load8 = [&](uint32_t jb, int32_t (&d)[8]) {
+        // rows are frameSize long and the plane is padded, so the (unused) over-read of the last block stays inside
+        const int4 t0 = *(const int4 *)(row + jb), t1 = *(const int4 *)(row + jb + 4);
+        d[0] = t0.x; d[1] = t0.y; d[2] = t0.z; d[3] = t0.w;
+        d[4] = t1.x; d[5] = t1.y; d[6] = t1.z; d[7] = t1.w;
+    };
+    int32_t dA[8], dB[8];
+    load8(16, dA);
+    auto step8 = [&](uint32_t jb, const int32_t (&cur)[8], int32_t (&nxt)[8]) {
+        load8(jb + 8, nxt);
+        int32_t o[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++) o[s2] = lms_step_dec_wide<T>(a, w, tp, cur[s2], chanbits);
+        if (active && jb < n) {
+            *(int4 *)(row + jb) = make_int4(o[0], o[1], o[2], o[3]);
+            *(int4 *)(row + jb + 4) = make_int4(o[4], o[5], o[6], o[7]);
+        }
+    };
+    for (uint32_t jb = 16; jb < nMax; jb += 16) {
+        step8(jb, dA, dB);
+        if (jb + 8 < nMax) step8(jb + 8, dB, dA);
+    }
+}
+
 // ---- fused launch: entropy waves first (they are resident before any follower can wait), predictor waves behind
 // them; last, one block per packet for the uncompressed elements (nobody waits for those: their dispatch hides under
 // the entropy chain instead of costing a launch of its own)
@@ -849,7 +986,16 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
         // classes) must not all land on the same few workgroups
         hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4093u ? da.numPackets : 4093u), dim3(256), 0, st, V);
         hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
-        hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
+        static const bool wide = [] { const char *v = getenv("ALAC_HIP_DEC_WIDE"); return !(v && v[0] == '0'); }();
+        if (wide) {
+            // chains sorted by tap count, one lane per chain (ALAC_HIP_DEC_WIDE=0: the two-lane kernel of the fused launch)
+            (void)hipMemsetAsync(V.prog + 2 * (uint64_t)da.numPackets, 0, 8, st);
+            hipLaunchKernelGGL(k_dec_classify, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, V);
+            hipLaunchKernelGGL(k_dec_unpc_wide<4>, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
+            hipLaunchKernelGGL(k_dec_unpc_wide<8>, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
+        } else {
+            hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
+        }
     }
     hipLaunchKernelGGL(k_dec_unpc, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
     switch (da.bitDepth) {

@@ -149,7 +149,8 @@ struct DecodeArgs {
 
 hipError_t launch_decode(const DecodeArgs &da, hipStream_t st);
 // second generation (alac_decode_v1.hip): `words` = capWords uint32 of scratch for the re-staged stream, `plane` =
-// numPackets * numChannels * frameSize int32, `prog` = 2 * numPackets uint32 (progress words of the fused launch)
+// numPackets * numChannels * frameSize int32, `prog` = 2 * numPackets + 2 uint32 (progress words of the fused launch;
+// chain list and its two counters where the stages are separate launches)
 hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
                             hipStream_t st);
 
