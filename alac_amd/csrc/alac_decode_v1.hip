@@ -341,7 +341,13 @@ struct EntLane {
 // library or Apple's encoder writes), so pb * x is two shifts; otherwise full 32-bit multiplies.
 // PUB: fused launch — the lane publishes how many residuals are complete every (pubMask + 1) rounds (drain,
 // agent-scope release, one flag store per channel) for the predictor waves that follow it.
-template <bool PB40, bool PUB>
+// WIDE (separate launches only): the residual stores of a round are DEFERRED by one round.  gfx9 counts loads and stores
+// in one counter (vmcnt), so the wait for the staged words a round fetched ahead also waited for the 4-byte stores the
+// symbols in between had just issued — a full write round trip under load, every 16 symbols (entropy kernel at 125 000
+// packets: 4.1 ms with the stores, 2.8 ms without them).  Here a round only RECORDS (position, value) per symbol; the
+// stores are issued at the start of the next round, right after the wait, and have a whole round to complete.  A symbol
+// that was not decoded repeats the lane's previous pair (same value to the same address: harmless).
+template <bool PB40, bool PUB, bool WIDE = false>
 __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, uint32_t *ringRow, uint64_t wordBase,
                                                uint32_t cur0, uint32_t bit0, uint32_t limit, uint64_t nbytes,
                                                uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV,
@@ -386,12 +392,36 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
             }
         }
     };
+    // WIDE: the pairs recorded by the previous round, as int32 indices from the lane's first row
+    uint32_t dpos[kDecRound];
+    int32_t dval[kDecRound];
+    uint32_t lastPos = 0;   // a coded lane's first row starts as zeros (pre-zeroed plane): (0, 0) is a harmless first pair
+    int32_t lastVal = 0;
+    uint32_t rowOff = 0;    // E.row - rowBase, in samples
+    int32_t *const rowBase = E.row;
+    const bool storer = E.active != 0;  // lanes without a coded packet never store (an escape packet's rows are k_dec_raw's)
+#pragma unroll
+    for (int k = 0; k < kDecRound; k++) {
+        dpos[k] = 0;
+        dval[k] = 0;
+    }
+    bool had = false;  // this lane decoded something in the round the pairs come from
+    auto store_deferred = [&]() {
+        if constexpr (WIDE) {
+            if (storer && had) {
+#pragma unroll
+                for (int k = 0; k < kDecRound; k++) rowBase[dpos[k]] = dval[k];
+            }
+            had = false;
+        }
+    };
     while (__any(E.active != 0)) {
         if (pending) {
             write16(pendBase, q);
             E.F = pendBase + 16;
             pending = false;
         }
+        store_deferred();  // behind the wait above, in front of the next fetch
         if (E.active && E.F - (bw.idx - 2u) <= 16) {
             fetch16(E.F, q);
             pending = true;
@@ -400,6 +430,10 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int it = 0; it < kDecRound; it++) {
+            if constexpr (WIDE) {
+                dpos[it] = lastPos;
+                dval[it] = lastVal;
+            }
             // still decoding, and >= 160 staged bits ahead of the window (one condition, one branch)
             if ((uint32_t)(E.active != 0) & (uint32_t)(E.F - bw.idx >= 4)) {
                 // ---- one residual: dyn_get_32bit (ag_dec.c:220-270), straight-line for the common case ----
@@ -424,7 +458,16 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                 bw_skip(bw, used);
                 const uint32_t nd = n + E.zmode;
                 // ((nd + 1) >> 1) * (nd odd ? -1 : 1); stored even when the packet just failed (c < numSamples still)
-                E.row[E.c] = (int32_t)((nd >> 1) ^ (0u - (nd & 1u)));
+                const int32_t val = (int32_t)((nd >> 1) ^ (0u - (nd & 1u)));
+                if constexpr (!WIDE) {
+                    E.row[E.c] = val;
+                } else {
+                    lastPos = rowOff + E.c;
+                    lastVal = val;
+                    had = true;
+                    dpos[it] = lastPos;
+                    dval[it] = val;
+                }
                 E.c++;
                 uint32_t mb = mul_pb(nd) + E.mb - (mul_pb(E.mb) >> kQBShift);
                 mb = n > kMeanClamp ? kMeanClamp : mb;
@@ -473,6 +516,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                             E.zmode = 0;
                             E.pb = pbV;
                             E.row += A.frameSize;
+                            rowOff += A.frameSize;
                         } else {
                             E.endPos = bw_pos(bw) - bit0;
                             E.active = 0;
@@ -484,10 +528,11 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         asm volatile("" ::: "memory");
         if (PUB && (++round & V.pubMask) == 0) publish();
     }
+    store_deferred();  // the last round's pairs
     publish();  // everything is complete (or failed): nobody waits for this lane any more
 }
 
-template <bool PUB>
+template <bool PUB, bool WIDE = false>
 __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block)
 {
     const DecodeArgs &A = V.d;
@@ -550,9 +595,9 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
 
     uint32_t *prog = (PUB && live) ? V.prog + (uint64_t)p * 2 : nullptr;
     if (__all(!coded || (pbU == 40 && pbV == 40)))
-        entropy_rounds<true, PUB>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<true, PUB, WIDE>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
     else
-        entropy_rounds<false, PUB>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<false, PUB, WIDE>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
 
     if (live && E.status != status0) {
         rec->status = E.status;
@@ -566,6 +611,13 @@ __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
 {
     __shared__ uint32_t ring[64 * kWinStride];
     entropy_body<false>(V, ring, blockIdx.x);
+}
+
+// the same with deferred residual stores (what the separate launches of a large batch use; ALAC_HIP_DEC_WIDE=0: the above)
+__global__ __launch_bounds__(64) void k_dec_entropy_wide(DecV1Args V)
+{
+    __shared__ uint32_t ring[64 * kWinStride];
+    entropy_body<false, true>(V, ring, blockIdx.x);
 }
 
 // ---- unpc_block (codec/dp_dec.c:55-381), in place over the chain's row ----
@@ -985,8 +1037,14 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
         // a prime number of workgroups: escape packets that recur with a period (every 8th packet of the benchmark's signal
         // classes) must not all land on the same few workgroups
         hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4093u ? da.numPackets : 4093u), dim3(256), 0, st, V);
-        hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
         static const bool wide = [] { const char *v = getenv("ALAC_HIP_DEC_WIDE"); return !(v && v[0] == '0'); }();
+        // deferred residual stores pay while a SIMD holds at most two entropy waves (measured, entropy kernel alone: 60 000
+        // packets 3.19 -> 2.51 ms, 125 000 4.06 -> 3.82, but 250 000 6.36 -> 6.86: with more waves per SIMD the other
+        // waves already cover the store round trips and the extra instructions only cost)
+        if (wide && nEnt <= 2048)
+            hipLaunchKernelGGL(k_dec_entropy_wide, dim3(nEnt), dim3(64), 0, st, V);
+        else
+            hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
         if (wide) {
             // chains sorted by tap count, one lane per chain (ALAC_HIP_DEC_WIDE=0: the two-lane kernel of the fused launch)
             (void)hipMemsetAsync(V.prog + 2 * (uint64_t)da.numPackets, 0, 8, st);
