@@ -292,20 +292,27 @@ class Context:
         return c[:n].copy()
 
     # ---- decode ----------------------------------------------------------------------------
-    def decode(self, cookie, stream, offsets, num_packets, zero_fill=True):
+    def decode(self, cookie, stream, offsets, num_packets, zero_fill=True, out=None):
         """stream: uint8 cuda tensor, offsets: int64 cuda tensor [num_packets+1].
         Returns (pcm uint8 tensor [num_packets*packet_bytes], num_samples int32, status int32).
         zero_fill=False leaves the bytes behind a short packet's samples uninitialised (the library writes
-        num_samples frames per packet and zeroes only failed packets) and saves a pass over the output."""
+        num_samples frames per packet and zeroes only failed packets) and saves a pass over the output.
+        out=(pcm, num_samples, status): write into these tensors instead of allocating (a timed loop that allocates
+        2 GB per call measures the allocator)."""
         with self._call() as cur:
             t = self.torch
             ck = np.ascontiguousarray(cookie, np.uint8)
             fmt = Format()
             self._check(self.lib.alac_hip_format_from_cookie(ck.ctypes.data, ck.size, C.byref(fmt)))
-            alloc = t.zeros if zero_fill else t.empty
-            pcm = alloc(num_packets * fmt.packet_bytes, dtype=t.uint8, device=self.device)
-            ns = t.zeros(num_packets, dtype=t.int32, device=self.device)
-            st = t.zeros(num_packets, dtype=t.int32, device=self.device)
+            if out is not None:
+                pcm, ns, st = out
+                if pcm.numel() < num_packets * fmt.packet_bytes or ns.numel() < num_packets or st.numel() < num_packets:
+                    raise ValueError("decode: output tensors too small")
+            else:
+                alloc = t.zeros if zero_fill else t.empty
+                pcm = alloc(num_packets * fmt.packet_bytes, dtype=t.uint8, device=self.device)
+                ns = t.zeros(num_packets, dtype=t.int32, device=self.device)
+                st = t.zeros(num_packets, dtype=t.int32, device=self.device)
             # sized from the stream actually handed over (ID_FIL / ID_DSE padding may exceed the regular bound)
             wsb = int(self.lib.alac_hip_decode_workspace_bytes_stream(C.byref(fmt), num_packets, int(stream.numel())))
             ws = self._workspace(wsb)
