@@ -974,6 +974,46 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
     constexpr uint32_t BPS = bytes_per_sample(DEPTH);
     const uint32_t och = V.outChannels;
     uint8_t *out = A.pcmOut + ((uint64_t)p * A.frameSize * och + V.outFirst) * BPS;
+    if constexpr (DEPTH == 16 && CH == 2) {
+        // the common shape (16-bit stereo into a stereo frame): four frames per thread — two 16-byte loads, one 16-byte
+        // store instead of 4-byte accesses (the kernel is a 6 GB stream at 125 000 packets)
+        if (och == 2 && (A.frameSize & 3) == 0) {
+            typedef int32_t I4 __attribute__((ext_vector_type(4), aligned(4)));
+            typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+            const uint32_t n4 = n & ~3u;
+            for (uint32_t j = ((blockIdx.x % bx) * blockDim.x + threadIdx.x) * 4; j < n4; j += bx * blockDim.x * 4) {
+                const I4 uu = *(const I4 *)(u + j), vv = *(const I4 *)(v + j);
+                U4 o;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int32_t l, r;
+                    if (mixRes != 0) {
+                        l = uu[k] + vv[k] - ((mixRes * vv[k]) >> mixBits);
+                        r = l - vv[k];
+                    } else {
+                        l = uu[k];
+                        r = vv[k];
+                    }
+                    o[k] = ((uint32_t)(uint16_t)l) | ((uint32_t)r << 16);
+                }
+                *(U4 *)(out + (uint64_t)j * 4) = o;
+            }
+            // the last n mod 4 frames of a short packet
+            for (uint32_t j = n4 + (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
+                const int32_t uu = u[j], vv = v[j];
+                int32_t l, r;
+                if (mixRes != 0) {
+                    l = uu + vv - ((mixRes * vv) >> mixBits);
+                    r = l - vv;
+                } else {
+                    l = uu;
+                    r = vv;
+                }
+                *(uint32_t *)(out + (uint64_t)j * 4) = ((uint32_t)(uint16_t)l) | ((uint32_t)r << 16);
+            }
+            return;
+        }
+    }
     for (uint32_t j = (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
         int32_t l, r = 0;
         if constexpr (CH == 2) {
