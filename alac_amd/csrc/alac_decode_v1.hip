@@ -886,29 +886,54 @@ __global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
     }
     int32_t tp = o16[15 - T];  // out[j - T - 1]
 
-    // ---- 8-step blocks; the residuals of block i + 1 are loaded while block i computes ----
+    // ---- 32-step blocks = one 128-byte line of the lane's row: the eight 16-byte loads of a block are issued back to back,
+    // so the line is fetched from L2 once (with two loads per 8 steps the line had left the L1 — 10 waves x 64 rows — before
+    // its next quarter was wanted: four L2 requests per line).  The residuals of block i + 1 are loaded while block i computes.
     const uint32_t nMax = wave_max_u32(n);
-    auto load8 = [&](uint32_t jb, int32_t (&d)[8]) {
-        // rows are frameSize long and the plane is padded, so the (unused) over-read of the last block stays inside
-        const int4 t0 = *(const int4 *)(row + jb), t1 = *(const int4 *)(row + jb + 4);
-        d[0] = t0.x; d[1] = t0.y; d[2] = t0.z; d[3] = t0.w;
-        d[4] = t1.x; d[5] = t1.y; d[6] = t1.z; d[7] = t1.w;
-    };
-    int32_t dA[8], dB[8];
-    load8(16, dA);
-    auto step8 = [&](uint32_t jb, const int32_t (&cur)[8], int32_t (&nxt)[8]) {
-        load8(jb + 8, nxt);
-        int32_t o[8];
+    auto load32 = [&](uint32_t jb, int32_t (&d)[32]) {
+        // rows are frameSize long and the plane is padded by 256 bytes: the (unused) over-read of the last block, at most
+        // 31 samples past the longest row, stays inside
 #pragma unroll
-        for (int s2 = 0; s2 < 8; s2++) o[s2] = lms_step_dec_wide<T>(a, w, tp, cur[s2], chanbits);
-        if (active && jb < n) {
-            *(int4 *)(row + jb) = make_int4(o[0], o[1], o[2], o[3]);
-            *(int4 *)(row + jb + 4) = make_int4(o[4], o[5], o[6], o[7]);
+        for (int q = 0; q < 8; q++) {
+            const int4 t = *(const int4 *)(row + jb + 4 * q);
+            d[4 * q] = t.x;
+            d[4 * q + 1] = t.y;
+            d[4 * q + 2] = t.z;
+            d[4 * q + 3] = t.w;
         }
     };
-    for (uint32_t jb = 16; jb < nMax; jb += 16) {
-        step8(jb, dA, dB);
-        if (jb + 8 < nMax) step8(jb + 8, dB, dA);
+    int32_t dA[32], dB[32];
+    if (32 < nMax) load32(32, dA);
+    if (16 < nMax) {
+        // samples 16 .. 31 on their own, so that the 32-step blocks start on a line boundary (rows of the usual frame sizes
+        // are 128-byte aligned)
+        int32_t d[16], o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int4 t = *(const int4 *)(row + 16 + 4 * q);
+            d[4 * q] = t.x;
+            d[4 * q + 1] = t.y;
+            d[4 * q + 2] = t.z;
+            d[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) o[s2] = lms_step_dec_wide<T>(a, w, tp, d[s2], chanbits);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (active && 16 + 4 * q < n) *(int4 *)(row + 16 + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+    auto step32 = [&](uint32_t jb, const int32_t (&cur)[32], int32_t (&nxt)[32]) {
+        if (jb + 32 < nMax) load32(jb + 32, nxt);
+        int32_t o[32];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) o[s2] = lms_step_dec_wide<T>(a, w, tp, cur[s2], chanbits);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (active && jb + 4 * q < n) *(int4 *)(row + jb + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    };
+    for (uint32_t jb = 32; jb < nMax; jb += 64) {
+        step32(jb, dA, dB);
+        if (jb + 32 < nMax) step32(jb + 32, dB, dA);
     }
 }
 
