@@ -88,6 +88,7 @@ struct EncLayout {
     uint64_t predStride;
     // tap-parallel pipeline: residual planes [sample][stream], decision scratch, working state
     uint64_t resA, resB, resC, bits1, cost2, state, flags, rowReady, cls, colChain;
+    uint64_t bitWordsB, bitsB;  // tiny batches only (0: absent): second coder wave of the split final coder
     uint32_t chainsPad, colsPad;
 };
 
@@ -142,6 +143,15 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2 * kMaxSubBatches) * 8, 256);
     L.colChain = off;
     off = align_up(off + (uint64_t)L.colsPad * 4, 256);
+    // Tiny batches (<= 4096 chains: a chained file, a few hundred files side by side; the four-lanes-per-chain regime of
+    // alac_encode_v1.hip): the final coder of a chain is split over two waves, the second one writes here
+    L.bitWordsB = L.bitsB = 0;
+    if (lanes <= 4096) {
+        L.bitWordsB = off;
+        off = align_up(off + ((uint64_t)numPackets + 1) * 2 * L.wcap * 4, 256);
+        L.bitsB = off;
+        off = align_up(off + ((uint64_t)numPackets + 1) * 2 * 4, 256);
+    }
     L.total = off;
     return L;
 }
@@ -617,6 +627,8 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
         vb.cls = ws + L.cls;
         vb.colChain = (uint32_t *)(ws + L.colChain);
         vb.colsPad = L.colsPad;
+        vb.bitWordsB = L.bitWordsB ? (uint32_t *)(ws + L.bitWordsB) : nullptr;
+        vb.bitsB = L.bitsB ? (uint32_t *)(ws + L.bitsB) : nullptr;
         vb.ho = handoff_ctl(ctx);
         e = launch_encode_v1(fmt->bit_depth, fmt->num_channels, ea, pa, vb, ctx->vs, num_packets, maxSeg, ctx->stream, ev);
     }

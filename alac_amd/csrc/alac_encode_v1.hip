@@ -83,6 +83,15 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.colChain = vb.colChain;
     A.colsPad = vb.colsPad;
     {
+        // ALAC_HIP_SPLIT_CODER=0: one coder wave per 64 chains also in the tiny-batch regime
+        static const bool split = [] { const char *v = getenv("ALAC_HIP_SPLIT_CODER"); return !(v && v[0] == '0'); }();
+        A.bitWordsB = split ? vb.bitWordsB : nullptr;
+        A.bitsB = vb.bitsB;
+        // the second wave first walks [0, splitAt) keeping only the coder's state (~half the instructions of coding), then
+        // codes the rest: both waves finish together at ~2/3 of the frame; whole 48-residual iterations of the coder loop
+        A.splitAt = (ea.frameSize * 2 / 3) / 48 * 48;
+    }
+    {
         static const uint32_t pm = [] {
             const char *v = getenv("ALAC_HIP_PUBFENCE");
             return (v && v[0] == '1') ? (0x80000000u | 3u) : 0u;

@@ -943,8 +943,14 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
 // two producers through the residual plane, 256 samples behind.  Both kinds are single-wave workgroups and
 // together (625 + 313 at 10k packets) still fit one per SIMD, so the ~1.0 ms and ~1.3 ms of the two stages
 // overlap instead of adding up.
-template <int DEPTH, int CH, int T = 4, int L = 2>
-__global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits)
+// SPLIT (tiny batches): the coder of 64 chains is TWO waves.  Workgroups [nLms, nLms + nCoder) code residuals [0, splitAt) of
+// their chains; workgroups [nLms + nCoder, nLms + 2 nCoder) first walk those residuals keeping only the coder's state
+// (mean, zero-run bookkeeping: about half the instructions of coding — the bit count of that pass is never read, so the
+// compiler drops everything that only feeds it), then code [splitAt, N) into a second slot.  A run that is open at the
+// split is closed by the second wave, which has counted its zeros from the start.  k_splice_split appends the second
+// string to the first afterwards.  A chained file is two chains: its packet position is as long as ONE coder chain.
+template <int DEPTH, int CH, int T = 4, int L = 2, bool SPLIT = false>
+__global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits, uint32_t nCoder = 0)
 {
     __shared__ LmsShared<L> sh;
     __shared__ uint32_t recip[17];
@@ -983,7 +989,9 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
     } else {
         gol_table_init(recip, lane);
         __syncthreads();
-        const uint32_t w = blockIdx.x - nLms;
+        const uint32_t cb = blockIdx.x - nLms;
+        const bool second = SPLIT && cb >= nCoder;
+        const uint32_t w = second ? cb - nCoder : cb;
         const uint32_t chain = A.S.segBegin * CH + w * 64u + lane;
         uint32_t p, N;
         bool active = seg_packet(A.S, chain / CH, p, N);
@@ -996,18 +1004,83 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         const uint64_t stride = A.chainsPad;
         GolF g;
         golf_reset(g);
-        uint32_t *slot = A.bitWords + (have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c) * A.wcap;
-        golf_open(g, slot, A.wcap);
+        const uint64_t slotIdx = have ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + c;
         RowWait wait;
         wait.producers(A.flagsF, L * w, L, nLms);
         wait.avail = 0;
         wait.base = 0;
         wait.ho = A.ho;
-        golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
-        golf_flush<true>(g);
-        if (active) rec->c[c].bits = golf_written_bits(g, slot);
+        if constexpr (!SPLIT) {
+            uint32_t *slot = A.bitWords + slotIdx * A.wcap;
+            golf_open(g, slot, A.wcap);
+            golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
+            golf_flush<true>(g);
+            if (active) rec->c[c].bits = golf_written_bits(g, slot);
+        } else {
+            const uint32_t a = A.splitAt;
+            const uint32_t nA = min(n, a), nB = n - nA;
+            if (!second) {
+                uint32_t *slot = A.bitWords + slotIdx * A.wcap;
+                golf_open(g, slot, A.wcap);
+                // a stream that ends inside this part is finished here; the others stay open for the second wave
+                golf_stream<true, true>(g, nA, wave_max(nA), chanBits, recip, one_plane(plane, stride, chain), wait,
+                                        A.idleFast != 0, n <= a);
+                golf_flush<true>(g);
+                if (active) rec->c[c].bits = golf_written_bits(g, slot);
+            } else {
+                // state only: nothing is written, the bit count is discarded
+                golf_stream<false, true>(g, nA, wave_max(nA), chanBits, recip, one_plane(plane, stride, chain), wait,
+                                         A.idleFast != 0, false);
+                g.bits = 0;
+                uint32_t *slot = A.bitWordsB + slotIdx * A.wcap;
+                golf_open(g, slot, A.wcap);
+                wait.base = a;
+                golf_stream<true, true>(g, nB, wave_max(nB), chanBits, recip, one_plane(plane + (uint64_t)a * stride, stride, chain),
+                                        wait, A.idleFast != 0, true);
+                golf_flush<true>(g);
+                if (have) A.bitsB[slotIdx] = (active && nB) ? golf_written_bits(g, slot) : 0u;
+            }
+        }
     }
 }
+
+// Append the second coder wave's bit string to the first (SPLIT above): one wave per chain slot of the position's packets.
+// The first string ends with a left-aligned partial word (golf_flush), the second starts at bit 0 of its slot.
+template <int CH>
+__global__ __launch_bounds__(64) void k_splice_split(V1Args A)
+{
+    const uint32_t chain = A.S.segBegin * CH + blockIdx.x;
+    uint32_t p, N;
+    if (!seg_packet(A.S, chain / CH, p, N)) return;
+    PacketRec *rec = A.recs + p;
+    if (rec->escape) return;
+    const uint32_t c = chain % CH;
+    const uint64_t slotIdx = (uint64_t)p * 2 + c;
+    const uint32_t lenA = rec->c[c].bits, lenB = A.bitsB[slotIdx];
+    if (lenB == 0) return;
+    uint32_t *dst = A.bitWords + slotIdx * A.wcap;
+    const uint32_t *src = A.bitWordsB + slotIdx * A.wcap;
+    const uint32_t first = lenA >> 5, keep = lenA & 31;                 // word the second string starts in, bits of it in use
+    const uint32_t last = min((lenA + lenB + 31) >> 5, A.wcap);         // beyond the slot: longer than the escape size anyway
+    const uint32_t nwB = (lenB + 31) >> 5;
+    for (uint32_t w = first + threadIdx.x; w < last; w += 64) {
+        // 32 bits of the second string from bit s (negative only in the first word)
+        const int32_t s = (int32_t)(w * 32u - lenA);
+        uint32_t v;
+        if (s >= 0) {
+            const uint32_t i = (uint32_t)s >> 5, sh = (uint32_t)s & 31;
+            const uint32_t x = src[i], y = (i + 1 < nwB) ? src[i + 1] : 0u;
+            v = sh ? ((x << sh) | (y >> (32 - sh))) : x;
+        } else {
+            v = src[0] >> (uint32_t)(-s);
+        }
+        // (bits behind the end of the second string are zeros already: its last word is left-aligned and zero-padded)
+        if (w == first && keep) v |= dst[w];
+        dst[w] = v;
+    }
+    if (threadIdx.x == 0) rec->c[c].bits = lenA + lenB;
+}
+
 
 // ================================================================================================
 // Final pass by packet class.  After k_decide2 a packet is (a) escaped — nothing left to predict or code, (b) all
@@ -1377,11 +1450,18 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 }
             } else if (narrow) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
-                hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sp, A, nLms16, chanBits);
+                if (A.bitWordsB && A.splitAt >= 48) {
+                    hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4, true>), dim3(nLms16 + 2 * cblocks), dim3(64), 0, sp, A, nLms16,
+                                       chanBits, cblocks);
+                    hipLaunchKernelGGL(k_splice_split<CH>, dim3(nseg * CH), dim3(64), 0, sp, A);
+                } else {
+                    hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sp, A, nLms16, chanBits,
+                                       0u);
+                }
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else if (fuse) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
-                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sp, A, nLms, chanBits);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sp, A, nLms, chanBits, 0u);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else {
                 hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sp, A);

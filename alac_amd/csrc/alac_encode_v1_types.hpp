@@ -56,6 +56,10 @@ struct V1Args {
     ClassInfo *cls;
     uint32_t *colChain;    // [colsPad] chain (segment * CH + channel) of every column, kNoChain for pad columns
     uint32_t colsPad;      // row stride of resC in the class layout
+    // coder split over two waves (tiny batches, k_final_fused): the second wave's bit words and bit counts
+    uint32_t *bitWordsB;   // same layout as bitWords; null: no split
+    uint32_t *bitsB;       // [2 * numPackets + 2] bits the second wave wrote per channel slot
+    uint32_t splitAt;      // residuals [0, splitAt) belong to the first wave
 };
 
 // search + final passes of every packet position, then finalize / scan / pack (alac_encode_v1_impl.hpp); explicitly

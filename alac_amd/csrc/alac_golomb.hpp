@@ -280,10 +280,12 @@ __device__ __forceinline__ RowSrc one_plane(const int32_t *plane, uint64_t strid
     return r;
 }
 
+// finish (per lane): the stream ends with these `n` residuals — a run still open is coded (golf_finish).  false where the
+// residuals continue elsewhere (the first part of a coder split over two waves, k_final_fused).
 template <bool WRITE, bool ZZ = false, class Need = NoWait, bool LAZY = false>
 __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
                                             const uint32_t *recip, const RowSrc &R, Need &&need = Need(),
-                                            bool idleFast = true)
+                                            bool idleFast = true, bool finish = true)
 {
     constexpr int B = 16;
     int32_t bufA[B], bufB[B], bufC[B];
@@ -353,7 +355,9 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
         load(bufB, jb + 4 * B);
         codeChecked(bufC, jb + 2 * B);
     }
-    golf_finish<WRITE, LAZY>(g, n > 0, recip);
+    const uint32_t openRun = g.inrun;
+    golf_finish<WRITE, LAZY>(g, n > 0 && finish, recip);
+    if (!finish) g.inrun = openRun;  // the run continues in the caller's next part
 }
 
 // functor form (any per-lane row choice), used only where lanes of one wave disagree about the planes

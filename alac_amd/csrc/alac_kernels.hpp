@@ -94,6 +94,8 @@ struct V1Buffers {
     void *cls;             // ClassInfo of the class-based final pass (alac_encode_v1.hip)
     uint32_t *colChain;    // [colsPad]
     uint32_t colsPad;      // chainsPad + 128 per possible sub-batch: row stride of resC
+    uint32_t *bitWordsB;   // tiny batches: bit words of the second coder wave (same layout as EncodeArgs::bitWords), else null
+    uint32_t *bitsB;       // [2 * numPackets + 2]
 };
 // side streams and fork/join events for the sub-batch overlap (owned by the context)
 constexpr uint32_t kMaxSubBatches = 8;

@@ -27,8 +27,10 @@ FILES = ["tests/test_gpu_encode.py", "tests/test_gpu_decode.py", "tests/test_gpu
     {"ALAC_HIP_THRU": "1", "ALAC_HIP_SUBBATCH": "2"},
     {"ALAC_HIP_OVERLAP_POS": "0"},
     {"ALAC_HIP_DEC_FUSED": "0", "ALAC_HIP_DEC_WIDE": "0"},
+    {"ALAC_HIP_SPLIT_CODER": "0"},
 ], ids=["first-generation", "unfused", "idle-checked", "release-fence", "two-lane-latency-regime", "throughput-regime",
-        "throughput-regime-sub-batches", "positions-not-overlapped", "unfused-two-lane-decode-predictor"])
+        "throughput-regime-sub-batches", "positions-not-overlapped", "unfused-two-lane-decode-predictor",
+        "tiny-batch-coder-not-split"])
 def test_variant_passes_the_parity_files(gpu_ctx, env):
     e = dict(os.environ)
     e.update(env)
