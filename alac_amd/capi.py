@@ -43,6 +43,8 @@ SIGNATURES = {
     "alac_hip_destroy": (None, [_vp]),
     "alac_hip_synchronize": (_i32, [_vp]),
     "alac_hip_last_error": (C.c_char_p, [_vp]),
+    "alac_hip_set_option": (_i32, [_vp, C.c_char_p, _i32]),
+    "alac_hip_get_option": (_i32, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "alac_hip_stream": (_vp, [_vp]),
     "alac_hip_encode_workspace_bytes": (_u64, [C.POINTER(Format), _u32, _u32]),
     "alac_hip_encode_max_output_bytes": (_u64, [C.POINTER(Format), _u32]),
@@ -203,6 +205,31 @@ class Context:
     def synchronize(self):
         self._check(self.lib.alac_hip_synchronize(self.h))
 
+    def set_option(self, key, value):
+        """alac_hip_set_option: pin a code path of this context (include/alac_hip.h lists the keys)"""
+        self._check(self.lib.alac_hip_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = _i32(0)
+        self._check(self.lib.alac_hip_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """context manager: set options for the duration of a with-block, then restore them"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return cm()
+
     def synth_pcm(self, first_frame, num_frames, fmt, out=None):
         """The synthetic PCM of frames [first_frame, first_frame + num_frames) generated ON THE DEVICE (same bytes as
         synth_pcm(): one generator source) -> uint8 cuda tensor."""
@@ -359,4 +386,6 @@ class Context:
             self._check(self.lib.alac_hip_dyn_decomp(self.h, mb0, pb, kb, bits.data_ptr(), stride, rows,
                                                      pc.data_ptr(), pc.shape[1], num_samples, max_size,
                                                      nb.data_ptr(), st.data_ptr()))
+            for x in (pc, nb, st):
+                x.record_stream(cur)  # allocated on self.stream, consumed on the caller's
             return pc, nb, st

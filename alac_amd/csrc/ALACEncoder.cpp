@@ -194,14 +194,20 @@ void ALACEncoder::InitializeSampling(void *d_ip, AudioFormatDescription theInput
         mBatchOffsets.resize(np + 1);
         ok = hipMemcpyAsync(mBatchSizes.data(), dSizes, np * 4ull, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipMemcpyAsync(mBatchOffsets.data(), dOffs, (np + 1) * 8ull, hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipMemcpyAsync(mState, dState, stateBytes, hipMemcpyDeviceToHost, st) == hipSuccess &&
-             hipStreamSynchronize(st) == hipSuccess;
+             hipMemcpyAsync(mState, dState, stateBytes, hipMemcpyDeviceToHost, st) == hipSuccess;
+        // alac_hip_synchronize, not a bare stream sync: it also reads the context's hand-off error word — a consumer wave
+        // that gave up waiting for its producer has coded garbage, and the batch must fail instead of being handed out
+        int32_t syncRc = ALAC_HIP_noErr;
+        if (ok) {
+            syncRc = alac_hip_synchronize(mCtx);
+            ok = syncRc == ALAC_HIP_noErr;
+        }
         if (ok) {
             mBatchStream.resize(mBatchOffsets[np]);
             ok = hipMemcpy(mBatchStream.data(), dOut, mBatchOffsets[np], hipMemcpyDeviceToHost) == hipSuccess;
         }
         if (ok) mStateValid = true;
-        mLastStatus = ok ? ALAC_noErr : kALAC_ParamError;
+        mLastStatus = ok ? ALAC_noErr : (syncRc != ALAC_HIP_noErr ? syncRc : kALAC_ParamError);
     }
     if (!ok) {
         mBatchStream.clear();

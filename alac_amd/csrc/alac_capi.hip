@@ -36,7 +36,61 @@ struct alac_hip_ctx {
     // store when a consumer's bounded wait runs out; read without a copy after a synchronize
     uint32_t *errHost = nullptr;
     uint32_t *errDev = nullptr;
+    // code-path switches of this context (alac_hip_set_option); defaults from the ALAC_HIP_* environment at creation
+    AlacOptions opt;
 };
+
+namespace alacdev {
+
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+AlacOptions alac_options_from_env()
+{
+    AlacOptions o;
+    o.thru = env_int("ALAC_HIP_THRU", o.thru);
+    o.idleFast = env_int("ALAC_HIP_IDLEFAST", o.idleFast);
+    o.wide81 = env_int("ALAC_HIP_WIDE81", o.wide81);
+    o.narrow = env_int("ALAC_HIP_NARROW", o.narrow);
+    o.splitCoder = env_int("ALAC_HIP_SPLIT_CODER", o.splitCoder) != 0;
+    o.pubFence = env_int("ALAC_HIP_PUBFENCE", o.pubFence) != 0;
+    o.overlapPos = env_int("ALAC_HIP_OVERLAP_POS", o.overlapPos) != 0;
+    o.fused = env_int("ALAC_HIP_FUSED", o.fused) != 0;
+    o.subBatch = env_int("ALAC_HIP_SUBBATCH", o.subBatch);
+    if (const char *e = getenv("ALAC_HIP_ENCODER")) o.laneEncoder = strcmp(e, "lane") == 0;
+    if (const char *e = getenv("ALAC_HIP_DECODER")) o.laneDecoder = strcmp(e, "lane") == 0;
+    if (const char *e = getenv("ALAC_HIP_DEC_FUSED")) o.decFused = *e ? (e[0] == '0' ? 0 : 1) : -1;
+    o.decWide = env_int("ALAC_HIP_DEC_WIDE", o.decWide) != 0;
+    o.decPubMask = env_int("ALAC_HIP_DEC_PUBMASK", o.decPubMask);
+    o.stageTaps = env_int("ALAC_HIP_STAGE_TAPS", o.stageTaps) != 0;
+    o.loseHandoff = env_int("ALAC_HIP_DEBUG_LOSE_HANDOFF", o.loseHandoff) == 1;
+    o.persist = env_int("ALAC_HIP_PERSIST", o.persist);
+    return o;
+}
+
+int32_t *alac_option_slot(AlacOptions &o, const char *key)
+{
+    if (!key) return nullptr;
+    static const struct { const char *name; int32_t AlacOptions::*slot; } table[] = {
+        {"thru", &AlacOptions::thru},           {"idlefast", &AlacOptions::idleFast},
+        {"wide81", &AlacOptions::wide81},       {"narrow", &AlacOptions::narrow},
+        {"split_coder", &AlacOptions::splitCoder}, {"pubfence", &AlacOptions::pubFence},
+        {"overlap_pos", &AlacOptions::overlapPos}, {"fused", &AlacOptions::fused},
+        {"subbatch", &AlacOptions::subBatch},   {"encoder_lane", &AlacOptions::laneEncoder},
+        {"decoder_lane", &AlacOptions::laneDecoder}, {"dec_fused", &AlacOptions::decFused},
+        {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask},
+        {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
+        {"persist", &AlacOptions::persist},
+    };
+    for (const auto &t : table)
+        if (strcmp(t.name, key) == 0) return &(o.*(t.slot));
+    return nullptr;
+}
+
+}  // namespace alacdev
 
 namespace {
 
@@ -67,8 +121,7 @@ HandoffCtl handoff_ctl(const alac_hip_ctx *ctx)
 {
     HandoffCtl h;
     h.err = ctx->errDev;
-    const char *v = getenv("ALAC_HIP_DEBUG_LOSE_HANDOFF");  // test switch: producers never publish, consumers give up fast
-    h.lose = (v && v[0] == '1') ? 1u : 0u;
+    h.lose = ctx->opt.loseHandoff ? 1u : 0u;  // test switch ("debug_lose_handoff"): producers never publish, consumers give up fast
     h.spinLimit = h.lose ? (1u << 8) : (1u << 22);
     return h;
 }
@@ -156,29 +209,18 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     return L;
 }
 
-// ALAC_HIP_ENCODER=lane selects the fused lane-per-chain kernel (alac_encode.hip); default is the
+// option "encoder_lane" selects the fused lane-per-chain kernel (alac_encode.hip); default is the
 // tap-parallel pipeline (alac_encode_v1.hip).  Both are HIP paths; there is no CPU path.
-// ALAC_HIP_SUBBATCH=n (1..8) overrides the number of overlapped sub-batches of the tap-parallel pipeline
-uint32_t sub_batches_requested()
+// option "subbatch" = n (1..8) overrides the number of overlapped sub-batches of the tap-parallel pipeline
+uint32_t sub_batches_requested(const alac_hip_ctx *ctx)
 {
-    static const uint32_t v = [] {
-        const char *e = getenv("ALAC_HIP_SUBBATCH");
-        int n = e ? atoi(e) : 0;  // 0 = default (v1_sub_batches: one; measured, no gain from more in either regime)
-        if (n < 0) n = 0;
-        if (n > (int)kMaxSubBatches) n = kMaxSubBatches;
-        return (uint32_t)n;
-    }();
-    return v;
+    int n = ctx->opt.subBatch;  // 0 = default (v1_sub_batches: one; measured, no gain from more in either regime)
+    if (n < 0) n = 0;
+    if (n > (int)kMaxSubBatches) n = kMaxSubBatches;
+    return (uint32_t)n;
 }
 
-bool use_lane_encoder()
-{
-    static const int v = [] {
-        const char *e = getenv("ALAC_HIP_ENCODER");
-        return (e && strcmp(e, "lane") == 0) ? 1 : 0;
-    }();
-    return v != 0;
-}
+bool use_lane_encoder(const alac_hip_ctx *ctx) { return ctx->opt.laneEncoder != 0; }
 
 // > 2 channels: the mono / stereo pipeline once per element over a gathered copy of its channels, then the splice
 // (alac_multichannel.hip)
@@ -288,14 +330,7 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets, uint64_t str
     return L;
 }
 
-bool use_lane_decoder()
-{
-    static const bool v = [] {
-        const char *e = getenv("ALAC_HIP_DECODER");
-        return e && strcmp(e, "lane") == 0;
-    }();
-    return v;
-}
+bool use_lane_decoder(const alac_hip_ctx *ctx) { return ctx->opt.laneDecoder != 0; }
 
 struct DevBuf {
     void *p = nullptr;
@@ -326,6 +361,7 @@ int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream)
     alac_hip_ctx *c = new (std::nothrow) alac_hip_ctx;
     if (!c) return ALAC_HIP_MemFullError;
     c->device = device;
+    c->opt = alac_options_from_env();
     if (hipSetDevice(device) != hipSuccess) {
         delete c;
         return ALAC_HIP_ParamError;
@@ -386,6 +422,24 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx)
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
     return check_handoff(ctx);
+}
+
+int32_t alac_hip_set_option(alac_hip_ctx *ctx, const char *key, int32_t value)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    int32_t *slot = alac_option_slot(ctx->opt, key);
+    if (!slot) return fail(ctx, ALAC_HIP_ParamError, "unknown option");
+    *slot = value;
+    return ALAC_HIP_noErr;
+}
+
+int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value)
+{
+    if (!ctx || !value) return ALAC_HIP_ParamError;
+    const int32_t *slot = alac_option_slot(ctx->opt, key);
+    if (!slot) return fail(ctx, ALAC_HIP_ParamError, "unknown option");
+    *value = *slot;
+    return ALAC_HIP_noErr;
 }
 
 const char *alac_hip_last_error(const alac_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -465,7 +519,7 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
     // the stereo batch runs on the context's stream, the mono batch beside it on a second stream (both are bound by
     // the latency of one wave, not by the machine)
     const bool both = M.g[0].count && M.g[1].count;
-    bool side = both && sub_batches_requested() <= 1;
+    bool side = both && sub_batches_requested(ctx) <= 1;
     if (side && !ctx->mcReady) {
         if (hipStreamCreateWithFlags(&ctx->mcStream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->mcFork, hipEventDisableTiming) != hipSuccess ||
@@ -581,7 +635,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
     if (timed && ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size())
         ev = &ctx->events[ctx->profCalls++ * EV];
     hipError_t e;
-    if (use_lane_encoder()) {
+    if (use_lane_encoder(ctx)) {
         if (ev) ctx->profSub.push_back(0);
         e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream,
                           ev ? ev + kMaxSubBatches * (kNumStages + 1) : nullptr);
@@ -596,7 +650,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
             if (!ok) return fail(ctx, ALAC_HIP_MemFullError, "creating side streams");
             ctx->vsReady = true;
         }
-        ctx->vs.numSub = sub_batches_requested();
+        ctx->vs.numSub = sub_batches_requested(ctx);
         if (ev) ctx->profSub.push_back(v1_sub_batches(num_segments, ctx->vs.numSub, fmt->num_channels));
         // packets per segment: the pipeline runs once per packet position (a chained segment is serial)
         uint32_t maxSeg = 1;
@@ -613,6 +667,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
             }
         }
         V1Buffers vb;
+        vb.opt = ctx->opt;
         vb.state = d_state ? d_state : (int16_t *)(ws + L.state);
         vb.stateInitialised = d_state && state_in;
         vb.resA = (int32_t *)(ws + L.resA);
@@ -821,8 +876,9 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.pb = ck[6];
     da.mb = ck[7];
     da.kb = ck[8];
-    // the kernels shift by kb and divide by what pb scales: a cookie outside what dyn_decomp accepts
-    // (codec/ag_dec.c:282-286 rejects kb / bit widths it cannot code) is a parameter error, not undefined shifts
+    // Local hardening, NOT reference behaviour (codec/ag_dec.c:282-286 only checks its pointers; ALACDecoder::Init takes any
+    // pb / mb / kb): the kernels shift by kb (k = min(lg3a, kb), m = (1 << k) - 1), so kb outside 1..16 would be an undefined
+    // or zero-width shift, and pb = 0 freezes the mean at values the quotient code does not expect.  No encoder writes either.
     if (da.kb < 1 || da.kb > 16 || da.pb == 0) return fail(ctx, ALAC_HIP_ParamError, "bad AG parameters in cookie (pb / kb)");
     da.maxElems = L.maxElems;
     da.recs = (DecRec *)(ws + L.recs);
@@ -831,8 +887,11 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.numSamplesOut = d_num_samples_out;
     da.statusOut = d_status;
     da.ho = handoff_ctl(ctx);
+    da.optFused = ctx->opt.decFused;
+    da.optWide = ctx->opt.decWide;
+    da.optPubMask = (uint32_t)ctx->opt.decPubMask;
     hipError_t e;
-    if (use_lane_decoder()) {
+    if (use_lane_decoder(ctx)) {
         e = launch_decode(da, ctx->stream);
     } else if (fmt.num_channels > 2) {
         // one pass per element of the channel count's sequence (the position of element k + 1 is only known once
@@ -873,7 +932,7 @@ int32_t alac_hip_pc_block(alac_hip_ctx *ctx, const int32_t *d_in, int32_t *d_pc,
         return fail(ctx, ALAC_HIP_ParamError, "bad pc_block parameters");
     if (numactive != 0 && numactive != 31 && !d_coefs) return fail(ctx, ALAC_HIP_ParamError, "null coefs");
     hipError_t e = launch_pc_block(d_in, d_pc, num_rows, row_stride, num, d_coefs, numactive, chanbits, denshift,
-                                   false, ctx->stream);
+                                   false, ctx->stream, ctx->opt.stageTaps != 0);
     return e == hipSuccess ? ALAC_HIP_noErr : fail(ctx, ALAC_HIP_ParamError, "pc_block launch", e);
 }
 

@@ -558,12 +558,12 @@ __global__ __launch_bounds__(64) void k_dyn_decomp(uint32_t mb0, uint32_t pb, ui
 
 hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
                            int16_t *coefs, int32_t numactive, uint32_t chanbits, uint32_t denshift, bool decode,
-                           hipStream_t st)
+                           hipStream_t st, bool allowTaps)
 {
     if (rows == 0) return hipSuccess;
     // encode direction, 5 taps and more: one chain per half wave, taps across the lanes (alac_stage_taps.hip);
-    // fewer taps, or shapes outside that kernel's exact range: one lane per row
-    static const bool noTaps = [] { const char *v = getenv("ALAC_HIP_STAGE_TAPS"); return v && v[0] == '0'; }();
+    // fewer taps, or shapes outside that kernel's exact range: one lane per row (option "stage_taps" = 0 forces it)
+    const bool noTaps = !allowTaps;
     if (decode) {
         hipLaunchKernelGGL(k_unpc_block, dim3((rows + 63) / 64), dim3(64), 0, st, in, pc, rows, stride, num, coefs,
                            numactive, chanbits, denshift);

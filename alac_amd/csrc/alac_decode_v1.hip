@@ -1101,7 +1101,7 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
     // enough that a stage is as slow as its longest serial chain; separate launches where every kernel fills the machine by
     // itself (no polling, no release fence per publish).  Measured at 125 000 packets: 17.6 ms fused, 12.5 ms separate;
     // at 10 000: 2.06 fused, 2.50 separate.  ALAC_HIP_DEC_FUSED=0/1 forces.
-    static const int forced = [] { const char *v = getenv("ALAC_HIP_DEC_FUSED"); return v ? (v[0] == '0' ? 0 : 1) : -1; }();
+    const int forced = V.d.optFused;
     const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= 65536;
     if (fused) {
         (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
@@ -1110,7 +1110,7 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
         // a prime number of workgroups: escape packets that recur with a period (every 8th packet of the benchmark's signal
         // classes) must not all land on the same few workgroups
         hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4093u ? da.numPackets : 4093u), dim3(256), 0, st, V);
-        static const bool wide = [] { const char *v = getenv("ALAC_HIP_DEC_WIDE"); return !(v && v[0] == '0'); }();
+        const bool wide = V.d.optWide != 0;
         // deferred residual stores pay while a SIMD holds at most two entropy waves (measured, entropy kernel alone: 60 000
         // packets 3.19 -> 2.51 ms, 125 000 4.06 -> 3.82, but 250 000 6.36 -> 6.86: with more waves per SIMD the other
         // waves already cover the store round trips and the extra instructions only cost)
@@ -1147,8 +1147,7 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
     V.capWords = capWords;
     V.plane = plane;
     V.prog = prog;
-    static const uint32_t pm = [] { const char *v = getenv("ALAC_HIP_DEC_PUBMASK"); return v ? (uint32_t)atoi(v) : 31u; }();
-    V.pubMask = pm;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
+    V.pubMask = da.optPubMask;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
     V.elemBit = nullptr;
     V.round = 0;
     V.outChannels = da.numChannels;

@@ -15,10 +15,9 @@ __global__ void k_init_state(int16_t *state, uint32_t numSegments)
 }
 
 // chains beyond what one 2-lane predictor wave per SIMD holds (1024 SIMDs x 32 chains x 2): throughput regime
-bool v1_throughput_regime(uint32_t numSegments, uint32_t channels)
+bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt)
 {
-    static const int forcedThru = [] { const char *v = getenv("ALAC_HIP_THRU"); return v ? atoi(v) : -1; }();
-    if (forcedThru >= 0) return forcedThru != 0;
+    if (opt.thru >= 0) return opt.thru != 0;
     return (uint64_t)numSegments * (channels > 2 ? 2 : channels) > 65536;
 }
 
@@ -62,14 +61,14 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         // Latency regime (about one wave per SIMD: up to ~2 x 1024 x 32 chains): idle lanes should not slow their
         // wave down.  With many waves per SIMD the machine is throughput bound and the extra work of idle lanes
         // costs more than the checked paths (measured: 125 000 packets 18.6 ms vs 20.3 ms).  ALAC_HIP_IDLEFAST=0/1 forces.
-        static const int forced = [] { const char *v = getenv("ALAC_HIP_IDLEFAST"); return v ? atoi(v) : -1; }();
+        const int forced = vb.opt.idleFast;
         const uint64_t chains = (uint64_t)ea.numSegments * channels;
         A.idleFast = forced >= 0 ? (uint32_t)forced : (chains <= 65536 ? 1u : 0u);
-        static const int forced81 = [] { const char *v = getenv("ALAC_HIP_WIDE81"); return v ? atoi(v) : -1; }();
-        A.thru = v1_throughput_regime(ea.numSegments, channels) ? 1u : 0u;
+        const int forced81 = vb.opt.wide81;
+        A.thru = v1_throughput_regime(ea.numSegments, channels, vb.opt) ? 1u : 0u;
         A.wide81 = forced81 >= 0 ? (uint32_t)forced81 : A.thru;
         if (forced < 0) A.idleFast = A.thru ? 0u : 1u;
-        static const int forcedNarrow = [] { const char *v = getenv("ALAC_HIP_NARROW"); return v ? atoi(v) : -1; }();
+        const int forcedNarrow = vb.opt.narrow;
         A.narrow = forcedNarrow >= 0 ? (uint32_t)forcedNarrow : (chains <= 4096 ? 1u : 0u);
     }
     A.packetBytes = ea.packetBytes;
@@ -84,7 +83,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.colsPad = vb.colsPad;
     {
         // ALAC_HIP_SPLIT_CODER=0: one coder wave per 64 chains also in the tiny-batch regime
-        static const bool split = [] { const char *v = getenv("ALAC_HIP_SPLIT_CODER"); return !(v && v[0] == '0'); }();
+        const bool split = vb.opt.splitCoder != 0;
         A.bitWordsB = split ? vb.bitWordsB : nullptr;
         A.bitsB = vb.bitsB;
         // the second wave first walks [0, splitAt) keeping only the coder's state (~half the instructions of coding), then
@@ -92,11 +91,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         A.splitAt = (ea.frameSize * 2 / 3) / 48 * 48;
     }
     {
-        static const uint32_t pm = [] {
-            const char *v = getenv("ALAC_HIP_PUBFENCE");
-            return (v && v[0] == '1') ? (0x80000000u | 3u) : 0u;
-        }();
-        A.pubMask = pm;
+        A.pubMask = vb.opt.pubFence ? (0x80000000u | 3u) : 0u;
     }
     if (!vb.stateInitialised)
         hipLaunchKernelGGL(k_init_state, dim3((ea.numSegments * 64 + 255) / 256), dim3(256), 0, st, vb.state,
@@ -104,9 +99,9 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
 #define V1_CASE(D)                                                                                   \
     case D:                                                                                          \
         if (channels == 2)                                                                           \
-            launch_v1_typed<D, 2>(A, numPackets, maxSegPackets, st, ev, pa, vs);                         \
+            launch_v1_typed<D, 2>(A, numPackets, maxSegPackets, st, ev, pa, vs, vb.opt);                 \
         else                                                                                         \
-            launch_v1_typed<D, 1>(A, numPackets, maxSegPackets, st, ev, pa, vs);                         \
+            launch_v1_typed<D, 1>(A, numPackets, maxSegPackets, st, ev, pa, vs, vb.opt);                 \
         break;
     switch (depth) {
         V1_CASE(16)

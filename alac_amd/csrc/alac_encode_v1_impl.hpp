@@ -1308,7 +1308,7 @@ __global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numP
 // ================================================================================================
 template <int DEPTH, int CH>
 void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st, hipEvent_t *ev,
-                     const PackArgs &pa, const V1Streams &vs)
+                     const PackArgs &pa, const V1Streams &vs, const AlacOptions &opt)
 {
     constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
     const uint32_t nsegAll = A0.S.numSegments;
@@ -1343,9 +1343,8 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
         // predictor waves wait, per chain, for rows that p's final pass still owns (rowReady).  The rest of p + 1 waits for
         // p's final pass.  58-75 % of packets choose 4 taps on both channels: their successor's search (a third of a
         // position's serial chain) disappears behind the final pass.
-        static const bool ovEnv = [] { const char *v = getenv("ALAC_HIP_OVERLAP_POS"); return !(v && v[0] == '0'); }();
-        const bool overlap = ovEnv && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
-                             A.S.frameSize / 8 < 65536u && [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
+        const bool overlap = opt.overlapPos != 0 && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
+                             A.S.frameSize / 8 < 65536u && opt.fused != 0;
         if (overlap) {
             A.rowReady = A0.ovRowReady;
             A.flagsF = A0.ovFlagsF;
@@ -1358,7 +1357,7 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             hipEvent_t *e = (evh && pos + 1 == maxSegPackets) ? evh : nullptr;
             const bool firstPos = pos == 0;
             if (e) (void)hipEventRecord(e[kStageLms1], sp);
-            static const bool fused = [] { const char *v = getenv("ALAC_HIP_FUSED"); return !(v && v[0] == '0'); }();
+            const bool fused = opt.fused != 0;
             // Two regimes (A.thru, set by launch_encode_v1 from the batch size):
             //  latency     at most ~one predictor wave per SIMD: a stage is as slow as its longest serial chain, so the
             //              predictor and the coder that trails it share ONE launch (producer/consumer through HBM) and a

@@ -66,6 +66,6 @@ struct V1Args {
 // instantiated for DEPTH in {16, 20, 24, 32} x CH in {1, 2}
 template <int DEPTH, int CH>
 void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st, hipEvent_t *ev,
-                     const PackArgs &pa, const V1Streams &vs);
+                     const PackArgs &pa, const V1Streams &vs, const AlacOptions &opt);
 
 }  // namespace alacdev

@@ -81,7 +81,34 @@ struct HandoffCtl {
     uint32_t lose = 0;
 };
 
+// Per-context switches that select code paths (alac_hip_set_option; the ALAC_HIP_* environment variables of the same
+// names are only the DEFAULTS a context starts from, read once in alac_hip_create).  -1 = automatic (chosen per call
+// from the batch shape).
+struct AlacOptions {
+    int32_t thru = -1;         // "thru"         ALAC_HIP_THRU        encode: throughput (1) / latency (0) regime
+    int32_t idleFast = -1;     // "idlefast"     ALAC_HIP_IDLEFAST    lanes without work do not force the checked paths
+    int32_t wide81 = -1;       // "wide81"       ALAC_HIP_WIDE81      8-tap search rows with all taps in one lane
+    int32_t narrow = -1;       // "narrow"       ALAC_HIP_NARROW      tiny batches: four lanes per chain
+    int32_t splitCoder = 1;    // "split_coder"  ALAC_HIP_SPLIT_CODER tiny batches: final coder of a chain on two waves
+    int32_t pubFence = 0;      // "pubfence"     ALAC_HIP_PUBFENCE    release fence per publish (instead of write-through rows)
+    int32_t overlapPos = 1;    // "overlap_pos"  ALAC_HIP_OVERLAP_POS chained batches: position p + 1's search beside p's final pass
+    int32_t fused = 1;         // "fused"        ALAC_HIP_FUSED       producer/consumer launches (latency regime)
+    int32_t subBatch = 0;      // "subbatch"     ALAC_HIP_SUBBATCH    overlapped sub-batches (0 = default: one)
+    int32_t laneEncoder = 0;   // "encoder_lane" ALAC_HIP_ENCODER=lane first-generation lane-per-chain encoder
+    int32_t laneDecoder = 0;   // "decoder_lane" ALAC_HIP_DECODER=lane first-generation decoder
+    int32_t decFused = -1;     // "dec_fused"    ALAC_HIP_DEC_FUSED   decode: entropy lanes || predictor waves in one launch
+    int32_t decWide = 1;       // "dec_wide"     ALAC_HIP_DEC_WIDE    decode, separate launches: one lane per chain, sorted by taps
+    int32_t decPubMask = 31;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols
+    int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
+    int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
+    int32_t persist = -1;      // "persist"      ALAC_HIP_PERSIST     chained tiny batches: one persistent launch per batch
+};
+AlacOptions alac_options_from_env();
+// nullptr for an unknown key
+int32_t *alac_option_slot(AlacOptions &o, const char *key);
+
 struct V1Buffers {
+    AlacOptions opt;
     HandoffCtl ho;
     int16_t *state;        // [segments][64] working coefficient rows (caller's d_state or workspace)
     bool stateInitialised; // rows already hold the caller's initial state
@@ -107,7 +134,7 @@ struct V1Streams {
 };
 // sub-batches actually used for a batch of numSegments segments
 uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels);
-bool v1_throughput_regime(uint32_t numSegments, uint32_t channels);
+bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt);
 // ev (nullable): (maxSub + 1) blocks of kNumStages + 1 events; block h < maxSub = sub-batch h's predictor /
 // Golomb stages on its own stream, block maxSub = finalize + scan + pack on the caller's stream
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
@@ -143,6 +170,8 @@ struct DecodeArgs {
     DecRec *recs;       // [maxElems][numPackets]
     const uint32_t *gate = nullptr;  // lane decoder as a fallback: its kernels do nothing unless *gate != 0
     HandoffCtl ho;
+    int32_t optFused = -1, optWide = 1;  // AlacOptions::decFused / decWide (host-side launch choices)
+    uint32_t optPubMask = 31;            // AlacOptions::decPubMask
     int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
     uint8_t *pcmOut;
     uint32_t *numSamplesOut;
@@ -201,7 +230,7 @@ hipError_t launch_decode_v1_elements(const DecodeArgs &da, const McElement *el, 
 // ---- stage-level ----
 hipError_t launch_pc_block(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num,
                            int16_t *coefs, int32_t numactive, uint32_t chanbits, uint32_t denshift,
-                           bool decode, hipStream_t st);
+                           bool decode, hipStream_t st, bool allowTaps = true);
 // tap-parallel pc_block for any tap count (alac_stage_taps.hip); *_ok tells whether the shape is in its exact range
 bool pc_block_taps_ok(int32_t num, int32_t na, uint32_t chanbits, uint32_t denshift);
 void launch_pc_block_taps(const int32_t *in, int32_t *pc, uint32_t rows, uint32_t stride, int32_t num, int16_t *coefs,

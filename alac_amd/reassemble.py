@@ -29,65 +29,80 @@ def _all_gather_flat(out, piece, group, gloo):
 
 class Reassembler:
     """Two-phase exchange for a pipelined caller (bench.py at N > 1): begin() enqueues the small collectives (shard
-    lengths, optionally packet sizes) and an asynchronous copy of the lengths to pinned host memory — no host wait;
-    finish(), called a step later, reads the lengths (long since arrived), posts the grouped send/receive of the shard
-    bytes at their final offsets.  The host therefore never blocks on the GPU between two encode steps.
-    All work is issued on the stream that is current when the methods are called."""
+    lengths and capacities, optionally packet sizes) and an asynchronous copy of the lengths to pinned host memory — no
+    host wait; finish(), called a step later, reads the lengths (long since arrived), posts the grouped send/receive of
+    the shard bytes at their final offsets.  The host therefore never blocks on the GPU between two encode steps.
+    All work is issued on the stream that is current when the methods are called.
 
-    def __init__(self, group=None):
+    The exchange MODE is a collective decision taken once, at construction: "direct" (grouped send/receive) unless any
+    rank asks for the padded all-gather (mode="allgather" or ALAC_REASSEMBLE=allgather on that rank) — the request is
+    all-reduced (MAX), so every rank runs the same sequence of collectives even if the ranks' environments differ.  A
+    failing exchange raises on the rank that sees it; nothing falls back to another collective from an except branch
+    (ranks that disagree about the next collective hang the job or place bytes wrongly).  Every precondition that can
+    raise in finish() is evaluated from the all-gathered (length, capacity) table, identical on all ranks, so the ranks
+    raise together, before any collective of that step."""
+
+    def __init__(self, group=None, mode=None):
+        import os
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.gloo = dist.get_backend(group) == "gloo"
         self.stream = None
-        # ALAC_REASSEMBLE=allgather (or a grouped send/receive that raises) falls back to the padded all-gather: every
-        # shard padded to the longest, one collective, then one copy per shard to its offset
-        import os
-        self.padded_mode = os.environ.get("ALAC_REASSEMBLE", "") == "allgather"
+        want = mode if mode is not None else os.environ.get("ALAC_REASSEMBLE", "")
+        if want not in ("", "direct", "allgather"):
+            raise ValueError(f"unknown re-assembly mode {want!r}")
+        flag = torch.tensor([1 if want == "allgather" else 0], dtype=torch.int32,
+                            device="cpu" if self.gloo else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        self.padded_mode = bool(flag.item())
         self.padded = None
 
     def begin(self, shard, length, sizes=None):
         """shard: 1-D uint8 tensor whose first `length` bytes are this rank's packets; length: int64 tensor with one
         element on the shard's device; sizes: optional int32 tensor [packets per rank] (the same count on every rank)."""
         dev = shard.device
-        lens = torch.empty(self.world, dtype=torch.int64, device=dev)
-        _all_gather_flat(lens, length.reshape(1).to(torch.int64), self.group, self.gloo)
+        mine = torch.stack([length.reshape(()).to(torch.int64), torch.tensor(shard.numel(), dtype=torch.int64, device=dev)])
+        table = torch.empty(2 * self.world, dtype=torch.int64, device=dev)
+        _all_gather_flat(table, mine, self.group, self.gloo)
+        table = table.view(self.world, 2)
+        lens = table[:, 0].contiguous()
         all_sizes = None
         if sizes is not None:
             all_sizes = torch.empty(self.world * sizes.numel(), dtype=sizes.dtype, device=dev)
             _all_gather_flat(all_sizes, sizes, self.group, self.gloo)
         if dev.type == "cuda":
-            lens_h = torch.empty(self.world, dtype=torch.int64, pin_memory=True)
-            lens_h.copy_(lens, non_blocking=True)
+            table_h = torch.empty((self.world, 2), dtype=torch.int64, pin_memory=True)
+            table_h.copy_(table, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record()
         else:
-            lens_h, ready = lens.clone(), None
-        return dict(shard=shard, lens=lens, lens_h=lens_h, ready=ready, sizes=all_sizes)
+            table_h, ready = table.clone(), None
+        return dict(shard=shard, lens=lens, table_h=table_h, ready=ready, sizes=all_sizes)
 
     def finish(self, h):
         if h["ready"] is not None:
             h["ready"].synchronize()  # the lengths were exchanged a step ago
-        lens_h, shard = h["lens_h"], h["shard"]
+        table_h, shard = h["table_h"], h["shard"]
+        lens_h, caps_h = table_h[:, 0], table_h[:, 1]
         dev = shard.device
+        # preconditions, from the gathered table only: every rank reaches the same verdict
+        if bool((lens_h > caps_h).any()) or bool((lens_h < 0).any()):
+            raise ValueError("a shard buffer is shorter than its declared length")
+        pad = max((int(lens_h.max().item()) + 15) // 16 * 16, 16)
+        if self.padded_mode and pad > int(caps_h.min().item()):
+            raise ValueError("padded all-gather: the longest shard rounded up to 16 bytes does not fit every rank's shard "
+                             "buffer")
         mine = int(lens_h[self.rank].item())
-        if mine > shard.numel():
-            raise ValueError("shard buffer shorter than its declared length")
         from .capi import shard_offsets  # the C-ABI's prefix sums (alac_hip_shard_offsets)
         offsets_h = torch.tensor(shard_offsets(lens_h.tolist()), dtype=torch.int64)
         total = int(offsets_h[-1].item())
         if self.stream is None or self.stream.numel() < total:
             self.stream = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
-        if not self.padded_mode:
-            try:
-                self._place_direct(shard, lens_h, offsets_h, mine)
-            except RuntimeError as e:  # a backend without grouped point-to-point: keep the job alive on the collective
-                import sys
-                print(f"alac_amd.reassemble: grouped send/receive failed ({e}); falling back to the padded all-gather",
-                      file=sys.stderr)
-                self.padded_mode = True
         if self.padded_mode:
-            self._place_padded(shard, lens_h, offsets_h)
+            self._place_padded(shard, lens_h, offsets_h, pad)
+        else:
+            self._place_direct(shard, lens_h, offsets_h, mine)
         return dict(stream=self.stream, total=total, lens=h["lens"], offsets=offsets_h, sizes=h["sizes"],
                     mode="padded all-gather" if self.padded_mode else "grouped send/recv")
 
@@ -107,10 +122,7 @@ class Reassembler:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()  # NCCL: orders the current stream behind the group; gloo: blocks until it has completed
 
-    def _place_padded(self, shard, lens_h, offsets_h):
-        pad = max((int(lens_h.max().item()) + 15) // 16 * 16, 16)
-        if pad > shard.numel():
-            raise ValueError("shard buffer shorter than the longest shard (padded all-gather)")
+    def _place_padded(self, shard, lens_h, offsets_h, pad):
         if self.padded is None or self.padded.numel() != self.world * pad:
             self.padded = torch.empty(self.world * pad, dtype=torch.uint8, device=shard.device)
         _all_gather_flat(self.padded, shard[:pad], self.group, self.gloo)
@@ -122,10 +134,10 @@ class Reassembler:
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
 
-def reassemble_shards(shard, length, group=None, cache=None, sizes=None):
+def reassemble_shards(shard, length, group=None, cache=None, sizes=None, mode=None):
     """One-shot form: returns dict(stream=<uint8 tensor, all shards in rank order>, total, lens=<int64[world]>,
     offsets=<int64[world+1]>, sizes).  `cache` (a previous return value) lets the stream buffer be reused."""
-    ra = cache["_ra"] if cache else Reassembler(group)
+    ra = cache["_ra"] if cache else Reassembler(group, mode)
     out = ra.finish(ra.begin(shard, length, sizes))
     out["_ra"] = ra
     return out

@@ -64,6 +64,20 @@ void alac_hip_destroy(alac_hip_ctx *ctx);
  * the outputs of those calls are then invalid (the decoder also marks the packets concerned kALAC_ParamError).  The
  * host-buffer entry points below return the same code themselves. */
 int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
+/* Code-path switches of ONE context (no reference counterpart: the reference has a single path).  The library picks a
+ * regime per call from the batch shape; a caller can pin one.  The ALAC_HIP_<KEY> environment variables only provide the
+ * defaults a context is created with.  value -1 = automatic where the key has an automatic mode.  Keys:
+ *   "thru" (-1/0/1)        encode: throughput regime (separate launches, 8 taps per lane, final pass per packet class)
+ *   "narrow" (-1/0/1)      encode: four lanes per chain (tiny batches, chained files)
+ *   "fused" (0/1)          encode: predictor || entropy coder as one producer/consumer launch (latency regime)
+ *   "idlefast", "wide81" (-1/0/1), "split_coder", "overlap_pos", "pubfence" (0/1), "subbatch" (0..8), "persist" (-1/0/1)
+ *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels
+ *   "dec_fused" (-1/0/1), "dec_wide" (0/1), "dec_pubmask"   decode launch shape
+ *   "stage_taps" (0/1)     alac_hip_pc_block: tap-parallel kernel for 5..30 taps
+ *   "debug_lose_handoff" (0/1)  test switch: producers of the in-launch hand-offs never publish
+ * Every setting produces the same bytes; only the kernels that run differ.  Unknown key -> kALAC_ParamError. */
+int32_t alac_hip_set_option(alac_hip_ctx *ctx, const char *key, int32_t value);
+int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value);
 /* Text of the last HIP/parameter error on this context ("" if none). */
 const char *alac_hip_last_error(const alac_hip_ctx *ctx);
 /* The stream the context enqueues on (hipStream_t as void*), for event timing by the caller. */

@@ -27,9 +27,14 @@ def ref():
 
 
 @pytest.fixture(scope="session")
-def gpu_ctx():
+def gpu_ctx(request):
+    """One context per test session.  tests/test_gpu_variants.py runs the parity files again as nested in-process sessions
+    whose config carries `alac_variant`: the code-path options (alac_hip_set_option) that session's context is pinned to."""
     import torch
     import alac_amd
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
-    return alac_amd.Context(0)
+    ctx = alac_amd.Context(0)
+    for k, v in getattr(request.config, "alac_variant", {}).items():
+        ctx.set_option(k, v)
+    return ctx

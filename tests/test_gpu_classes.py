@@ -35,3 +35,18 @@ def test_reference_call_sequence(harness, oracle, tmp_path, bits, ch, frames):
     assert np.array_equal(got_sizes, ref_sizes)
     assert np.array_equal(got, ref)
     assert (tmp_path / "back.pcm").read_bytes() == pcm
+
+
+def test_class_path_reports_a_lost_handoff(harness, tmp_path):
+    """the drop-in ALACEncoder batch path (InitializeSampling -> Encode(index), what alacconvert uses) must fail
+    when a consumer wave of an in-launch hand-off gave up, not hand out corrupt packets with ALAC_noErr.  The context the
+    class creates takes ALAC_HIP_DEBUG_LOSE_HANDOFF as its default: InitializeSampling's LastStatus is the error
+    (harness exit code 5)."""
+    frames = 4096 * 5 + 321
+    pcm = music_like(frames, 2, 16, seed=18)
+    (tmp_path / "in.pcm").write_bytes(pcm)
+    env = dict(os.environ, ALAC_HIP_DEBUG_LOSE_HANDOFF="1")
+    p = subprocess.run([harness, "16", "2", "44100", str(tmp_path / "in.pcm"), str(tmp_path / "s.bin"),
+                        str(tmp_path / "z.bin"), str(tmp_path / "back.pcm")], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 5, (p.returncode, p.stdout, p.stderr)
+    assert not (tmp_path / "s.bin").exists()

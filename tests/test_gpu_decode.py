@@ -172,8 +172,7 @@ def test_stream_beyond_the_workspace_fails_cleanly(gpu_ctx, oracle):
     assert rc == 0
     gpu_ctx.synchronize()
     st = st.cpu().tolist()
-    import os
-    if os.environ.get("ALAC_HIP_DECODER") == "lane":
+    if gpu_ctx.get_option("decoder_lane"):
         # the first-generation decoder reads the packets where they lie (no staged copy): everything decodes
         assert st == [0] * n
         assert np.array_equal(out.cpu().numpy(), pcm)

@@ -1,39 +1,58 @@
 """The alternative code paths behind the same C-ABI must pass the same parity tests: the first-generation
-lane-per-chain encoder / decoder (ALAC_HIP_ENCODER=lane, ALAC_HIP_DECODER=lane) and the un-fused launches
-(ALAC_HIP_FUSED=0, ALAC_HIP_DEC_FUSED=0, ALAC_HIP_IDLEFAST=0), and the regimes the batch size normally selects: the small
-batches of the parity files run on the four-lanes-per-chain mapping by default, so ALAC_HIP_NARROW=0 puts them on the
-two-lane kernels of the 10 000-packet benchmark and ALAC_HIP_THRU=1 on the throughput regime's separate launches, class
-compaction, 8-taps-in-a-lane search and lazy word stores.  The switches are read once per process, so each
-variant runs the parity files in a child process."""
+lane-per-chain encoder / decoder (options encoder_lane / decoder_lane), the un-fused launches (fused = 0, dec_fused = 0,
+idlefast = 0), and the regimes the batch size normally selects: the small batches of the parity files run on the
+four-lanes-per-chain mapping by default, so narrow = 0 puts them on the two-lane kernels of the 10 000-packet benchmark
+and thru = 1 on the throughput regime's launches (class compaction, 8-taps-in-a-lane search, lazy word stores; DESIGN.md
+4.0).  The switches are per-context options (alac_hip_set_option), so every variant runs IN THIS PROCESS: a nested pytest
+session over the parity files whose `gpu_ctx` fixture (tests/conftest.py) creates a context pinned to the variant."""
 import os
-import subprocess
-import sys
 
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FILES = ["tests/test_gpu_encode.py", "tests/test_gpu_decode.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_multichannel.py",
-         "tests/test_gpu_wholefile.py"]
+         "tests/test_gpu_wholefile.py", "tests/test_gpu_chained.py"]
+
+VARIANTS = {
+    "first-generation": {"encoder_lane": 1, "decoder_lane": 1},
+    "unfused": {"fused": 0, "dec_fused": 0},
+    "idle-checked": {"idlefast": 0},
+    "release-fence": {"pubfence": 1},
+    "two-lane-latency-regime": {"narrow": 0},
+    "throughput-regime": {"thru": 1},
+    "throughput-regime-sub-batches": {"thru": 1, "subbatch": 2},
+    "positions-not-overlapped": {"overlap_pos": 0},
+    "unfused-two-lane-decode-predictor": {"dec_fused": 0, "dec_wide": 0},
+    "tiny-batch-coder-not-split": {"split_coder": 0},
+    "chained-not-persistent": {"persist": 0},
+}
 
 
-@pytest.mark.parametrize("env", [
-    {"ALAC_HIP_ENCODER": "lane", "ALAC_HIP_DECODER": "lane"},
-    {"ALAC_HIP_FUSED": "0", "ALAC_HIP_DEC_FUSED": "0"},
-    {"ALAC_HIP_IDLEFAST": "0"},
-    {"ALAC_HIP_PUBFENCE": "1"},
-    {"ALAC_HIP_NARROW": "0"},
-    {"ALAC_HIP_THRU": "1"},
-    {"ALAC_HIP_THRU": "1", "ALAC_HIP_SUBBATCH": "2"},
-    {"ALAC_HIP_OVERLAP_POS": "0"},
-    {"ALAC_HIP_DEC_FUSED": "0", "ALAC_HIP_DEC_WIDE": "0"},
-    {"ALAC_HIP_SPLIT_CODER": "0"},
-], ids=["first-generation", "unfused", "idle-checked", "release-fence", "two-lane-latency-regime", "throughput-regime",
-        "throughput-regime-sub-batches", "positions-not-overlapped", "unfused-two-lane-decode-predictor",
-        "tiny-batch-coder-not-split"])
-def test_variant_passes_the_parity_files(gpu_ctx, env):
-    e = dict(os.environ)
-    e.update(env)
-    p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + FILES,
-                       cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+class _Variant:
+    """plugin of the nested session: hands the options to conftest's gpu_ctx and counts what ran"""
+
+    def __init__(self, opts):
+        self.opts = opts
+        self.passed = self.failed = 0
+        self.reports = []
+
+    def pytest_configure(self, config):
+        config.alac_variant = self.opts
+
+    def pytest_runtest_logreport(self, report):
+        if report.when == "call" and report.passed:
+            self.passed += 1
+        if report.failed:
+            self.failed += 1
+            self.reports.append(f"{report.nodeid}: {report.longreprtext[-1500:]}")
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_variant_passes_the_parity_files(gpu_ctx, name):
+    plug = _Variant(VARIANTS[name])
+    files = [os.path.join(ROOT, f) for f in FILES if os.path.exists(os.path.join(ROOT, f))]
+    rc = pytest.main(["-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "--no-header", "-W", "ignore::pytest.PytestAssertRewriteWarning"] + files,
+                     plugins=[plug])
+    assert rc == 0 and plug.failed == 0, "\n".join(plug.reports)
+    assert plug.passed > 50  # the files really ran (a collection error would also give rc != 0)
