@@ -5,7 +5,7 @@ plus the C++ ALACEncoder/ALACDecoder classes).  This package is the thin Python 
 the tests and bench.py; it never falls back to a CPU implementation.
 """
 from .capi import (AlacError, Context, Format, LIB_PATH, SIGNATURES, load_library, make_format,  # noqa: F401
-                   shard_offsets, shard_range, synth_pcm)
+                   shard_offsets, shard_range, source_fingerprint, synth_pcm)
 
 __all__ = ["AlacError", "Context", "Format", "LIB_PATH", "SIGNATURES", "load_library", "make_format",
-           "shard_offsets", "shard_range", "synth_pcm"]
+           "shard_offsets", "shard_range", "source_fingerprint", "synth_pcm"]

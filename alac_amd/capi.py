@@ -43,6 +43,7 @@ SIGNATURES = {
     "alac_hip_destroy": (None, [_vp]),
     "alac_hip_synchronize": (_i32, [_vp]),
     "alac_hip_last_error": (C.c_char_p, [_vp]),
+    "alac_hip_encode_regime": (C.c_char_p, [_vp, C.POINTER(Format), _u32]),
     "alac_hip_set_option": (_i32, [_vp, C.c_char_p, _i32]),
     "alac_hip_get_option": (_i32, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "alac_hip_stream": (_vp, [_vp]),
@@ -99,6 +100,23 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def source_fingerprint():
+    """sha256 (first 16 hex digits) over the kernel and C-ABI sources under alac_amd/csrc + include/: what a set of PMC
+    counters under profiles/ was collected on (bench.py refuses counters of other sources; no GPU or library needed)"""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = []
+    for d in (os.path.join(_HERE, "csrc"), os.path.join(root, "include")):
+        for dp, _, fn in os.walk(d):
+            files += [os.path.join(dp, f) for f in fn if f.endswith((".hip", ".hpp", ".h", ".cpp", ".c"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def shard_range(num_units, world, rank):
@@ -204,6 +222,10 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.alac_hip_synchronize(self.h))
+
+    def regime(self, fmt, num_segments):
+        """alac_hip_encode_regime: "throughput" / "latency" / "tiny" / "lane" for a batch of independent segments"""
+        return self.lib.alac_hip_encode_regime(self.h, C.byref(fmt), int(num_segments)).decode()
 
     def set_option(self, key, value):
         """alac_hip_set_option: pin a code path of this context (include/alac_hip.h lists the keys)"""

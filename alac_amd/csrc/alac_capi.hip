@@ -442,6 +442,17 @@ int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value)
     return ALAC_HIP_noErr;
 }
 
+const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt, uint32_t num_segments)
+{
+    if (!ctx || !format_ok(fmt)) return "";
+    if (use_lane_encoder(ctx)) return "lane";
+    const uint32_t ch = fmt->num_channels > 2 ? 2 : fmt->num_channels;
+    if (v1_throughput_regime(num_segments, ch, ctx->opt)) return "throughput";
+    const uint64_t chains = (uint64_t)num_segments * ch;
+    const bool narrow = ctx->opt.narrow >= 0 ? ctx->opt.narrow != 0 : chains <= 4096;
+    return (narrow && ctx->opt.fused) ? "tiny" : "latency";
+}
+
 const char *alac_hip_last_error(const alac_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 void *alac_hip_stream(const alac_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

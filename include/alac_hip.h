@@ -78,6 +78,10 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  * Every setting produces the same bytes; only the kernels that run differ.  Unknown key -> kALAC_ParamError. */
 int32_t alac_hip_set_option(alac_hip_ctx *ctx, const char *key, int32_t value);
 int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value);
+/* The encode regime this context would pick for a batch of num_segments independent segments of this format (a static
+ * string): "throughput" (separate launches, 64 chains per wave), "latency" (producer/consumer launches, two lanes per
+ * chain), "tiny" (four lanes per chain: chained files) or "lane" (first-generation kernel).  For reporting. */
+const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt, uint32_t num_segments);
 /* Text of the last HIP/parameter error on this context ("" if none). */
 const char *alac_hip_last_error(const alac_hip_ctx *ctx);
 /* The stream the context enqueues on (hipStream_t as void*), for event timing by the caller. */

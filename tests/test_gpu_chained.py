@@ -1,0 +1,47 @@
+"""Many EQUAL chained segments side by side — the shape of `alacconvert --batch` (files x packets) and of
+tools/chain_timing.py — in the tiny-batch regime (four lanes per chain, consecutive packet positions overlapped, final coder
+split over two waves).  64 segments x 32 packets is the shape at which a development build of round 2 raised a GPU memory
+access fault (the cause); 1024 x 32 = 2048 chains sits at the upper end of the regime, 1100 x 3 is
+ragged against every 16- / 32- / 64-chain wave boundary.  Every packet is compared with the oracle's chain."""
+import numpy as np
+import pytest
+
+import alac_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(gpu_ctx, oracle, fmt, nseg, per, sample_segments, expect_regime="tiny"):
+    import torch
+    n = nseg * per
+    assert gpu_ctx.regime(fmt, nseg) == expect_regime or gpu_ctx.get_option("narrow") == 0 or gpu_ctx.get_option("thru") == 1 \
+        or gpu_ctx.get_option("encoder_lane") == 1
+    pcm = alac_amd.synth_pcm(3, n, fmt)
+    seg_first = torch.arange(0, n + 1, per, dtype=torch.int32).cuda()
+    state = torch.zeros((nseg, 64), dtype=torch.int16).cuda()
+    stream, sizes = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n, seg_first=seg_first, state=state)
+    offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+    assert offs[-1] == len(stream)
+    enc = oracle.encoder(fmt.frame_size, fmt.bit_depth, fmt.num_channels)
+    for s in sample_segments:
+        a, b = s * per, (s + 1) * per
+        enc.reset()
+        ref, rs = enc.encode_stream(pcm[a * fmt.packet_bytes:b * fmt.packet_bytes], per * fmt.frame_size, 0)
+        assert np.array_equal(sizes[a:b], rs), s
+        assert np.array_equal(stream[offs[a]:offs[b]], ref), s
+        assert np.array_equal(state[s].cpu().numpy(), enc.get_state()), s
+
+
+def test_64_segments_x_32_packets(gpu_ctx, oracle):
+    _check(gpu_ctx, oracle, alac_amd.make_format(4096, 16, 2), 64, 32, range(64))
+
+
+def test_1024_segments_x_32_packets(gpu_ctx, oracle):
+    _check(gpu_ctx, oracle, alac_amd.make_format(4096, 16, 2), 1024, 32, [0, 1, 7, 8, 15, 16, 31, 32, 33, 511, 512, 1000, 1022, 1023])
+
+
+@pytest.mark.parametrize("depth,channels", [(16, 2), (24, 2), (16, 1)])
+def test_ragged_segment_count(gpu_ctx, oracle, depth, channels):
+    nseg = 1100 if channels == 2 else 2100
+    _check(gpu_ctx, oracle, alac_amd.make_format(1024, depth, channels), nseg, 3,
+           [0, 1, 2, 7, 8, 15, 16, 17, 31, 32, 63, 64, nseg // 2, nseg - 18, nseg - 17, nseg - 16, nseg - 2, nseg - 1])
