@@ -68,6 +68,8 @@ AlacOptions alac_options_from_env()
     o.stageTaps = env_int("ALAC_HIP_STAGE_TAPS", o.stageTaps) != 0;
     o.loseHandoff = env_int("ALAC_HIP_DEBUG_LOSE_HANDOFF", o.loseHandoff) == 1;
     o.persist = env_int("ALAC_HIP_PERSIST", o.persist);
+    o.classFused = env_int("ALAC_HIP_CLASS_FUSED", o.classFused) != 0;
+    o.searchFused = env_int("ALAC_HIP_SEARCH_FUSED", o.searchFused) != 0;
     return o;
 }
 
@@ -83,7 +85,8 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"decoder_lane", &AlacOptions::laneDecoder}, {"dec_fused", &AlacOptions::decFused},
         {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask},
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
-        {"persist", &AlacOptions::persist},
+        {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
+        {"search_fused", &AlacOptions::searchFused},
     };
     for (const auto &t : table)
         if (strcmp(t.name, key) == 0) return &(o.*(t.slot));

@@ -473,11 +473,15 @@ struct ChainJob {
 // A pass = one pc_block call over every chain of the wave: `num` samples adapt the row, residual positions
 // j < P go to dst[j * streamStride + stream] when store is set.
 // ZZ: residuals leave as their zig-zag image 2|del| - (del < 0) (what the final entropy coder starts from)
-template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false, int T = 4>
+// Sink: where the residual tile goes.  NoSink = the HBM plane `dst` (the flush below); any other type is a functor
+// sink(j0, row) called once per tile with the lane's own LDS row (row[i] = residual of position j0 + i, i < TILE; only
+// meaningful for LPC = 1 where lane == slot): the residuals never leave the CU (k_class_final).
+struct NoSink {};
+template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false, int T = 4, class Sink = NoSink>
 __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[T],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
                                          uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0,
-                                         StageRegs<CH, LPC> *head = nullptr, int headMode = 0)
+                                         StageRegs<CH, LPC> *head = nullptr, int headMode = 0, Sink *sink = nullptr)
 {
     // head / headMode: the raw PCM of the first tile is the same for every pass a kernel makes over a packet
     // (only the mix weights change): mode 1 keeps it in *head, mode 2 re-mixes it from there instead of loading
@@ -563,7 +567,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 if constexpr (WT) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *q = v;
             };
-            if ((uint32_t)(j0 + Geo<LPC>::TILE) <= fPmin) {
+            if constexpr (!std::is_same<Sink, NoSink>::value) {
+                static_assert(LPC == 1, "a tile sink reads the lane's own row");
+                (*sink)(j0, sh.xs + fs * Geo<LPC>::STRIDE);
+            }
+            if (!std::is_same<Sink, NoSink>::value && !dst) {
+                // the sink was the only consumer (k_class_final): no residual plane
+            } else if ((uint32_t)(j0 + Geo<LPC>::TILE) <= fPmin) {
                 // every lane owns every row of the tile: scalar row base + lane column, no predicate, no branch
                 int32_t *tileBase = dst + (uint64_t)j0 * streamStride;
 #pragma unroll
@@ -1083,6 +1093,149 @@ __global__ __launch_bounds__(64) void k_splice_split(V1Args A)
 
 
 // ================================================================================================
+// Throughput regime: the searches with their dyn_comp bit counts IN THE LANE that predicts (one lane per chain, 64 chains per
+// wave, CoderSink<false> below).  k_lms_search1<8, 1> -> k_gol_count1 and k_lms_search2<.., 1, .., 1> -> k_gol_count2 give lane i
+// of wave w the same chain, so the planes between them (5 + 2 planes: 2.6 GB written and 2.5 GB read per 125 000-packet
+// pass) moved every lane's residuals from the lane to itself.  Only the mixRes = 4 pass still leaves its residuals in HBM
+// (plane 4 of resA): the numUV decision counts them behind the first P2 residuals of the converge passes — the stale
+// predictor tail of codec/ALACEncoder.cu:433-445.
+// ================================================================================================
+// The lane codes (WRITE) or only counts (!WRITE) each 32-step tile straight from its own LDS row, where the predictor leaves
+// the residuals in place (lms_pass): the residuals never leave the CU.
+template <bool WRITE, bool LAZY>
+struct CoderSink {
+    GolF &g;
+    uint32_t n;         // this lane's residual count (0: no chain)
+    uint32_t nMaxWave;  // longest stream of the wave
+    uint32_t nMinWave;  // shortest (lanes without a chain count as 0 unless idleFast)
+    uint32_t bitSize;
+    const uint32_t *recip;
+    __device__ __forceinline__ void operator()(int j0, const int32_t *row)
+    {
+        constexpr int B = 16;
+#pragma unroll 1
+        for (int o = 0; o < Geo<1>::TILE; o += B) {
+            const uint32_t jb = (uint32_t)(j0 + o);
+            if (jb >= nMaxWave) break;  // wave-uniform
+            int32_t buf[B];
+#pragma unroll
+            for (int s = 0; s < B; s++) buf[s] = row[o + s];
+            if (jb + B <= nMinWave) {
+#pragma unroll
+                for (int s = 0; s < B; s++) golf_sym<WRITE, false, false, LAZY>(g, buf[s], true, bitSize, recip);
+            } else {
+#pragma unroll
+                for (int s = 0; s < B; s++) golf_sym<WRITE, true, false, LAZY>(g, buf[s], jb + s < n, bitSize, recip);
+            }
+        }
+    }
+};
+
+
+template <int DEPTH>
+__global__ __launch_bounds__(64, 2) void k_search1_lane(V1Args A, uint32_t chanBits)
+{
+    __shared__ LmsShared<1> sh;
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    gol_table_init(recip, lane);
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * 2 + blockIdx.x * 64u + (uint32_t)lane;
+    J.seg = chain >> 1;
+    J.ch = chain & 1;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = 8;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
+    int32_t a[8];
+    load_row<1, 8>(J, a, lane);
+    const uint32_t n8 = J.active ? J.N / 8 : 0;
+    const uint32_t nMax = wave_max(n8), nMin = wave_min_u32(n8);  // a lane without residuals puts the wave on the checked path
+    for (int r = 0; r <= kMaxRes; r++) {
+        lms_setup<1>(sh, J, r, lane);
+        GolF g;
+        golf_reset(g);
+        CoderSink<false, false> sink{g, n8, nMax, nMin, chanBits, recip};
+        // only the last pass (mixRes = 4) also leaves its residuals in HBM: k_search2_lane counts its tail
+        lms_pass<DEPTH, 2, 1, false, false, 8, CoderSink<false, false>>(sh, A, J, a, J.N / 8, J.N / 8, true, r == kMaxRes ? A.resA : nullptr,
+                                                                        5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
+                                                                        nullptr, 0, nullptr, 0, &sink);
+        golf_finish<false>(g, n8 > 0, recip);
+        if (J.active) A.bits1[(uint32_t)r * A.chainsPad + chain] = g.bits;
+    }
+    store_row<1, 8>(J, a, lane);
+}
+
+// converge passes of one row set (RS = 0: row 3 / 4 taps, RS = 1: row 7 / 8 taps) + the numUV cost of the row, one lane per chain
+template <int DEPTH, int CH, int RS>
+__device__ __forceinline__ void search2_lane_body(LmsShared<1> &sh, const uint32_t *recip, const V1Args &A, uint32_t block, int lane,
+                                                  uint32_t chanBits)
+{
+    constexpr int T = RS ? 8 : 4;
+    ChainJob J;
+    const uint32_t chain = A.S.segBegin * CH + block * 64u + (uint32_t)lane;
+    J.seg = chain / CH;
+    J.ch = chain % CH;
+    J.active = seg_packet(A.S, J.seg, J.p, J.N);
+    J.na = T;
+    J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + RS * 16;
+    int32_t a[T];
+    load_row<1, T>(J, a, lane);
+    const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
+    lms_setup<1>(sh, J, best, lane);
+    const uint32_t n8 = J.N / 8, n32 = J.N / 32;
+    uint32_t P2 = n8;  // residuals of the last converge pass that the count reads (k_gol_count2)
+    if (CH == 2) {
+        P2 = n32 > (uint32_t)(T + 1) ? n32 : (uint32_t)(T + 1);
+        P2 = P2 < n8 ? P2 : n8;
+    }
+    if (!J.active) P2 = 0;
+    GolF g;
+    golf_reset(g);
+    for (int pass = 0; pass < 8; pass++) {
+        const bool last = pass == 7;
+        const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
+        if (last) {
+            CoderSink<false, false> sink{g, P2, wave_max(P2), wave_min_u32(P2), chanBits, recip};
+            lms_pass<DEPTH, CH, 1, false, false, T, CoderSink<false, false>>(sh, A, J, a, num, P2, true, nullptr, 0, chain, lane, nullptr, 0,
+                                                                             nullptr, 0, &sink);
+        } else {
+            lms_pass<DEPTH, CH, 1, false, false, T>(sh, A, J, a, num, 0, false, nullptr, 0, chain, lane);
+        }
+    }
+    store_row<1, T>(J, a, lane);
+    if (CH == 2) {
+        // the tail [P2, n8) comes from the mixRes = 4 search pass (plane 4 of resA), codec/ALACEncoder.cu:433-445
+        const int32_t *planeA = A.resA + (uint64_t)kMaxRes * A.chainsPad;
+        const uint64_t strideA = 5ull * A.chainsPad;
+        const uint32_t nTail = J.active ? n8 - P2 : 0;
+        const uint32_t p2lo = wave_min_u32(J.active ? P2 : 0xffffffffu), p2hi = wave_max(J.active ? P2 : 0u);
+        if (p2lo >= p2hi) {
+            // (idleFast off: a lane whose stream ended with the converge pass must not count rows of the tail)
+            golf_stream<false>(g, nTail, wave_max(nTail), chanBits, recip, one_plane(planeA + (uint64_t)p2hi * strideA, strideA, chain),
+                               NoWait(), false);
+        } else {
+            golf_stream_fn<false>(g, nTail, wave_max(nTail), chanBits, recip,
+                                  [&](uint32_t j) { return (planeA + (uint64_t)(P2 + j) * strideA)[chain]; }, NoWait(), false);
+        }
+    } else {
+        golf_finish<false>(g, P2 > 0, recip);
+    }
+    if (J.active) A.cost2[(uint32_t)RS * A.chainsPad + chain] = g.bits * 8 + 16 * T;  // :438, :447 / :899
+}
+
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(64, 2) void k_search2_lane(V1Args A, uint32_t nb3, uint32_t chanBits)
+{
+    __shared__ LmsShared<1> sh;
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    if (blockIdx.x < nb3)
+        search2_lane_body<DEPTH, CH, 0>(sh, recip, A, blockIdx.x, threadIdx.x, chanBits);
+    else
+        search2_lane_body<DEPTH, CH, 1>(sh, recip, A, blockIdx.x - nb3, threadIdx.x, chanBits);
+}
+
+// ================================================================================================
 // Final pass by packet class.  After k_decide2 a packet is (a) escaped — nothing left to predict or code, (b) all
 // channels on 4 taps, (c) at least one channel on 8 taps.  The v1 final launch ran every chain of the batch on the
 // 2-lanes-x-4-taps mapping; here the chains are compacted per class so that each class gets the lane mapping that fits
@@ -1278,6 +1431,44 @@ __global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits,
     if (active) rec->c[c].bits = golf_written_bits<LAZY>(g, slot);
 }
 
+// ---- k_class_final: final predictor pass AND final entropy coder of a chain in ONE lane (throughput regime).
+// k_class_pred<.., T, 1> and k_class_coder give lane i the same column col0 + i, so the residual plane between them
+// (4.1 GB written and read again per 125 000-packet pass) only moved every lane's residuals from the lane to itself.
+// Here the lane codes each 32-step tile straight from its own LDS row (where the predictor leaves the residuals in place,
+// alac_lms.hpp / lms_pass): no resC, no transposed flush, no row loads, and the wave carries two independent serial
+// recurrences (sign-LMS and the Golomb mean tracker) instead of one.
+template <int DEPTH, int CH, int T>
+__global__ __launch_bounds__(64, 2) void k_class_final(V1Args A, uint32_t chanBits, uint32_t region)
+{
+    __shared__ LmsShared<1> sh;
+    __shared__ uint32_t recip[17];
+    const int lane = threadIdx.x;
+    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
+    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * 64u;
+    if (col0 >= (region ? nCols : base4)) return;
+    gol_table_init(recip, lane);
+    ChainJob J;
+    int best;
+    const uint32_t col = col0 + (uint32_t)lane;
+    class_job<CH>(A, col, region ? base4 + n4 : n8, J, best);
+    const uint32_t N = J.N;  // 0 for a column without a chain
+    PacketRec *rec = A.recs + J.p;
+    GolF g;
+    golf_reset(g);
+    uint32_t *slot = A.bitWords + (J.active ? (uint64_t)J.p * 2 + J.ch : (uint64_t)A.dumpSlot + (lane & 1)) * A.wcap;
+    golf_open(g, slot, A.wcap);
+    CoderSink<true, true> sink{g, N, wave_max(N), wave_min_u32(N ? N : (A.idleFast ? 0xffffffffu : 0u)), chanBits, recip};
+    int32_t a[T];
+    load_row<1>(J, a, lane);
+    lms_setup<1>(sh, J, best, lane);
+    lms_pass<DEPTH, CH, 1, false, false, T, CoderSink<true, true>>(sh, A, J, a, N, N, true, nullptr, 0, col, lane, nullptr, 0, nullptr,
+                                                                   0, &sink);
+    store_row<1>(J, a, lane);
+    golf_finish<true, true>(g, N > 0, recip);
+    golf_flush<true, true>(g);
+    if (J.active) rec->c[J.ch].bits = golf_written_bits<true>(g, slot);
+}
+
 // packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)
 template <int DEPTH, int CH>
 __global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numPackets, uint32_t frameSize)
@@ -1393,6 +1584,11 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                         hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
                                            cblocks, chanBits);
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
+                } else if (thru && wide && opt.searchFused) {
+                    // predictor passes and their bit counts in one lane: no residual planes except the mixRes = 4 pass's
+                    hipLaunchKernelGGL((k_search1_lane<DEPTH>), dim3(cblocks), dim3(64), 0, sp, A, chanBits);
+                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+                    if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else {
                     if (wide)
                         hipLaunchKernelGGL((k_lms_search1<DEPTH, 8, 1>), dim3(nLms1), dim3(64), 0, sp, A);
@@ -1411,13 +1607,16 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
             if (narrow)
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
+            else if (thru && opt.searchFused)  // as below, and every lane counts its own residuals
+                hipLaunchKernelGGL((k_search2_lane<DEPTH, CH>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3, chanBits);
             else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
             else
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
             if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
             if (e) (void)hipEventRecord(e[kStageGol2], sp);
-            hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+            if (!(thru && opt.searchFused) || narrow)
+                hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
             hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             if (overlap) (void)hipEventRecord(vs.stagger[pos & 1], sp);
             if (e) (void)hipEventRecord(e[kStageLms3], sp);
@@ -1438,14 +1637,25 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                     (void)hipEventRecord(vs.fork, sp);
                     (void)hipStreamWaitEvent(s2, vs.fork, 0);
                 }
-                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sp, A, 0u);
-                hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
-                if (e) (void)hipEventRecord(e[kStageGol3], sp);
-                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
-                hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
-                if (two) {
-                    (void)hipEventRecord(vs.join[0], s2);
-                    (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                if (opt.classFused) {
+                    // predictor and coder of a chain in one lane: no residual plane (k_class_final)
+                    hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
+                    hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                    if (two) {
+                        (void)hipEventRecord(vs.join[0], s2);
+                        (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                    }
+                    if (e) (void)hipEventRecord(e[kStageGol3], sp);
+                } else {
+                    hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sp, A, 0u);
+                    hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
+                    if (e) (void)hipEventRecord(e[kStageGol3], sp);
+                    hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
+                    hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                    if (two) {
+                        (void)hipEventRecord(vs.join[0], s2);
+                        (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                    }
                 }
             } else if (narrow) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);

@@ -363,7 +363,7 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
 // functor form (any per-lane row choice), used only where lanes of one wave disagree about the planes
 template <bool WRITE, class Fetch, class Need = NoWait>
 __device__ __forceinline__ void golf_stream_fn(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
-                                            const uint32_t *recip, Fetch &&fetch, Need &&need = Need())
+                                            const uint32_t *recip, Fetch &&fetch, Need &&need = Need(), bool idleFast = true)
 {
     constexpr int B = 16;
     int32_t bufA[B], bufB[B], bufC[B];
@@ -376,7 +376,7 @@ __device__ __forceinline__ void golf_stream_fn(GolF &g, uint32_t n, uint32_t nMa
     };
     // lanes without a stream (n = 0: pad lanes, escape packets) do not count: in the unchecked blocks they code
     // whatever they load into state and bit words nobody reads (their wp points at a spare slot)
-    const uint32_t nMinWave = wave_min_u32(n ? n : 0xffffffffu);
+    const uint32_t nMinWave = wave_min_u32(n ? n : (idleFast ? 0xffffffffu : 0u));
     auto code = [&](const int32_t (&buf)[B], uint32_t jb) {
         if (jb >= nMaxWave) return;
         if (jb + B <= nMinWave) {  // every lane that has a stream owns the whole block

@@ -101,6 +101,8 @@ struct AlacOptions {
     int32_t decPubMask = 31;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols
     int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
     int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
+    int32_t searchFused = 1;   // "search_fused" ALAC_HIP_SEARCH_FUSED throughput regime: search passes + their bit counts in one lane
+    int32_t classFused = 1;    // "class_fused"  ALAC_HIP_CLASS_FUSED throughput regime: final predictor + coder of a chain in one lane
     int32_t persist = -1;      // "persist"      ALAC_HIP_PERSIST     chained tiny batches: one persistent launch per batch
 };
 AlacOptions alac_options_from_env();
