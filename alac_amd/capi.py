@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libalac_hip.so")
+LIB_PATH = os.environ.get("ALAC_HIP_LIB") or os.path.join(_HERE, "libalac_hip.so")  # ALAC_HIP_LIB: A/B runs against another build
 SYNTH_PATH = os.path.join(_HERE, "libalac_synth.so")
 
 STATE_INT16 = 64
@@ -44,6 +44,7 @@ SIGNATURES = {
     "alac_hip_synchronize": (_i32, [_vp]),
     "alac_hip_last_error": (C.c_char_p, [_vp]),
     "alac_hip_encode_regime": (C.c_char_p, [_vp, C.POINTER(Format), _u32]),
+    "alac_hip_debug_waves_offset": (_u64, [C.POINTER(Format), _u32, _u32]),
     "alac_hip_set_option": (_i32, [_vp, C.c_char_p, _i32]),
     "alac_hip_get_option": (_i32, [_vp, C.c_char_p, C.POINTER(_i32)]),
     "alac_hip_stream": (_vp, [_vp]),

@@ -70,6 +70,9 @@ AlacOptions alac_options_from_env()
     o.persist = env_int("ALAC_HIP_PERSIST", o.persist);
     o.classFused = env_int("ALAC_HIP_CLASS_FUSED", o.classFused) != 0;
     o.searchFused = env_int("ALAC_HIP_SEARCH_FUSED", o.searchFused) != 0;
+    o.fold = env_int("ALAC_HIP_FOLD", o.fold);
+    o.ldsPad = env_int("ALAC_HIP_LDS_PAD", o.ldsPad);
+    o.initState = env_int("ALAC_HIP_INIT_STATE", o.initState) != 0;
     return o;
 }
 
@@ -86,7 +89,9 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask},
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
         {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
-        {"search_fused", &AlacOptions::searchFused},
+        {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"lds_pad", &AlacOptions::ldsPad},
+        {"debug_waves", &AlacOptions::debugWaves},
+        {"init_state", &AlacOptions::initState},
     };
     for (const auto &t : table)
         if (strcmp(t.name, key) == 0) return &(o.*(t.slot));
@@ -445,6 +450,12 @@ int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value)
     return ALAC_HIP_noErr;
 }
 
+uint64_t alac_hip_debug_waves_offset(const alac_hip_format *fmt, uint32_t num_packets, uint32_t num_segments)
+{
+    if (!format_ok(fmt) || fmt->num_channels > 2) return 0;
+    return enc_layout(fmt, num_packets, num_segments ? num_segments : num_packets).rowReady;
+}
+
 const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt, uint32_t num_segments)
 {
     if (!ctx || !format_ok(fmt)) return "";
@@ -684,6 +695,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
         vb.opt = ctx->opt;
         vb.state = d_state ? d_state : (int16_t *)(ws + L.state);
         vb.stateInitialised = d_state && state_in;
+        vb.stateInternal = d_state == nullptr;
         vb.resA = (int32_t *)(ws + L.resA);
         vb.resB = (int32_t *)(ws + L.resB);
         vb.resC = (int32_t *)(ws + L.resC);

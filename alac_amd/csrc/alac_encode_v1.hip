@@ -93,7 +93,13 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     {
         A.pubMask = vb.opt.pubFence ? (0x80000000u | 3u) : 0u;
     }
-    if (!vb.stateInitialised)
+    A.flags2 = vb.flags;
+    A.dbg = vb.opt.debugWaves ? vb.rowReady : nullptr;  // (the row-ready words are only used by chained tiny batches)
+    A.foldDecide = 0;
+    // rows that live in the workspace and hold no caller state are never read before they are written: the kernels of the first
+    // packet position take init_coefs as constants (load_row) instead of a k_init_state launch writing them first
+    A.virgin = (!vb.stateInitialised && vb.stateInternal) ? 1u : 0u;
+    if (!vb.stateInitialised && (!A.virgin || vb.opt.initState))
         hipLaunchKernelGGL(k_init_state, dim3((ea.numSegments * 64 + 255) / 256), dim3(256), 0, st, vb.state,
                            ea.numSegments);
 #define V1_CASE(D)                                                                                   \

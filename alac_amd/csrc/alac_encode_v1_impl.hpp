@@ -77,7 +77,30 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// One wave per workgroup: its LDS operations execute in program order, so phases that hand data through LDS
+// ---- wave roles of the producer / consumer launches ----
+// Every wave of these launches is an independent worker (a predictor wave or a coder wave) that wants a SIMD to itself: at
+// 10 000 packets the final launch has 938 of them for 1024 SIMDs, and a wave that shares its SIMD runs at ~0.8 of its speed
+// and decides when the launch ends.  As single-wave workgroups their SIMD was up to the CU's wave allocator, whose state the
+// kernels before leave behind: tools/wave_map.py (round 3) found 14-26 SIMDs with two waves and as many empty whenever an
+// unrelated small launch was added or removed upstream, +23 % on the launch.  A workgroup's OWN waves are dealt round the
+// CU's four SIMDs, so the workers are launched as workgroups of kWavesPerWg = 4 waves with consecutive worker ids
+// (worker = 4 * workgroup + wave): one per SIMD by construction while the launch has at most one workgroup per CU.
+constexpr int kWavesPerWg = 4;
+struct Worker {
+    uint32_t id;   // global worker (wave) index of the launch
+    int lane;      // lane inside the wave
+    int slot;      // wave inside the workgroup: which LDS block is this worker's
+};
+__device__ __forceinline__ Worker worker_id()
+{
+    Worker w;
+    w.slot = (int)(threadIdx.x >> 6);
+    w.id = blockIdx.x * (uint32_t)kWavesPerWg + (uint32_t)w.slot;
+    w.lane = (int)(threadIdx.x & 63);
+    return w;
+}
+
+// One wave per worker: its LDS operations execute in program order, so phases that hand data through LDS
 // only need the compiler not to reorder them (a real fence would also drain the global loads and stores that
 // are deliberately left in flight across the tile's compute).
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
@@ -140,7 +163,7 @@ struct RowWait {
             __builtin_amdgcn_s_sleep(16);
         }
         if (avail < rows) {
-            if (ho.err && threadIdx.x == 0) __hip_atomic_store(ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (ho.err && (threadIdx.x & 63) == 0) __hip_atomic_store(ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             avail = 0xffffffffu;  // stop polling: the call is already lost
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -612,12 +635,63 @@ __device__ __forceinline__ void lms_setup(LmsShared<LPC> &sh, const ChainJob &J,
     lds_order();
 }
 
+// virgin (wave-uniform): the rows have never been written — this is the first packet position of a call whose coefficient
+// state lives in the workspace — so the row IS init_coefs (codec/dp_enc.c:49-60: 38, -29, -2 scaled by 2^9 / 16) and the
+// k_init_state launch that used to write it is not needed
 template <int LPC, int T = 4>
-__device__ __forceinline__ void load_row(const ChainJob &J, int32_t (&a)[T], int lane)
+__device__ __forceinline__ void load_row(const ChainJob &J, int32_t (&a)[T], int lane, bool virgin = false)
 {
     const int h = lane & (LPC - 1);
 #pragma unroll
-    for (int i = 0; i < T; i++) a[i] = (J.active && T * h + i < J.na) ? (int32_t)J.row[T * h + i] : 0;
+    for (int i = 0; i < T; i++) {
+        const int k = T * h + i;
+        const int32_t init = k == 0 ? 1216 : (k == 1 ? -928 : (k == 2 ? -64 : 0));
+        a[i] = (J.active && k < J.na) ? (virgin ? init : (int32_t)J.row[k]) : 0;
+    }
+}
+
+// codec/ALACEncoder.cu:374-380: first minimum of bits1 + bits2 over mixRes 0..4 (what k_decide1 did; every wave that needs the
+// packet's mixRes after the search picks it itself: ten loads)
+__device__ __forceinline__ int pick_mixres(const V1Args &A, uint32_t seg)
+{
+    uint32_t best = 0, minb = 1u << 31;
+#pragma unroll
+    for (uint32_t r = 0; r <= (uint32_t)kMaxRes; r++) {
+        const uint32_t tot = A.bits1[r * A.chainsPad + seg * 2] + A.bits1[r * A.chainsPad + seg * 2 + 1];
+        if (tot < minb) {
+            minb = tot;
+            best = r;
+        }
+    }
+    return (int)best;
+}
+
+// numU / numV and the escape estimate of one packet (codec/ALACEncoder.cu:438-461, mono :899-915): what k_decide2 computes,
+// as a function so that the waves of a final launch that folds the decision in (k_final_fused<.., FOLD>) can evaluate it
+// themselves from the cost words of the search
+struct PacketDecision {
+    uint32_t num[2];
+    uint32_t escape;
+};
+template <int DEPTH, int CH>
+__device__ __forceinline__ PacketDecision decide_packet(const V1Args &A, uint32_t seg, uint32_t N)
+{
+    constexpr uint32_t SHB = bytes_shifted(DEPTH);
+    PacketDecision D;
+    D.num[1] = 0;
+    uint32_t minBits = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)CH; c++) {
+        const uint32_t chain = seg * CH + c;
+        const uint32_t c4 = A.cost2[chain], c8 = A.cost2[A.chainsPad + chain];
+        D.num[c] = c8 < c4 ? 8 : 4;
+        minBits += c8 < c4 ? c8 : c4;
+    }
+    const uint32_t partial = (N != A.S.frameSize);
+    minBits += (CH == 2 ? 64 : 32) + (partial ? 32 : 0) + N * (SHB * 8) * CH;
+    const uint32_t escapeBits = N * DEPTH * CH + (partial ? 32 : 0) + 16;
+    D.escape = minBits >= escapeBits ? 1u : 0u;
+    return D;
 }
 
 template <int LPC, int T = 4>
@@ -664,7 +738,7 @@ __device__ __forceinline__ void search1_predictor(LmsShared<L> &sh, const V1Args
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     int32_t a[T];
-    load_row<L>(J, a, lane);
+    load_row<L>(J, a, lane, A.virgin != 0);
     const uint32_t n8 = J.N / 8;
     // The raw PCM of the first tile is the same for all five passes; keeping it in registers spares each pass the one
     // load whose latency nothing hides — worth ~50 registers where a wave has its SIMD to itself.  The 64-chain mapping of
@@ -695,8 +769,10 @@ __global__ __launch_bounds__(64, L == 1 ? 2 : 1) void k_lms_search1(V1Args A)
 // ---- k_lms_search2: converge passes for numUV = 4 (row 3, one lane per chain) and 8 (row 7, two lanes per
 // chain) in one launch: the first nb3 workgroups take the 4-tap rows (codec/ALACEncoder.cu:420-431; mono :881-893)
 // RS = 0: row 3 (numUV = 4), RS = 1: row 7 (numUV = 8); T taps per lane x LPC lanes per chain
-template <int DEPTH, int CH, int RS, int T, int LPC>
-__device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane)
+// PUB (k_search2_fused): the last pass stores its rows written through and publishes them tile by tile in *flag for the count
+// waves of the same launch
+template <int DEPTH, int CH, int RS, int T, int LPC, bool PUB = false>
+__device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane, uint32_t *flag = nullptr)
 {
     constexpr int SLOTS = 64 / LPC;
     constexpr int rs = RS;
@@ -708,8 +784,10 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
     J.na = rs ? 8 : 4;
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + rs * 16;
     int32_t a[T];
-    load_row<LPC>(J, a, lane);
-    const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
+    // row 3 is first touched here; row 7 of a stereo packet comes from the mixRes search, of a mono packet from nowhere
+    load_row<LPC>(J, a, lane, A.virgin != 0 && (rs == 0 || CH == 1));
+    const int best = (CH == 2 && J.active) ? pick_mixres(A, J.seg) : 0;
+    if (CH == 2 && rs == 1 && J.active && J.ch == 0 && (lane % LPC) == 0) A.recs[J.p].mixRes = (uint32_t)best;
     lms_setup<LPC>(sh, J, best, lane);
     const uint32_t n8 = J.N / 8, n32 = J.N / 32;
     StageRegs<CH, LPC> head;
@@ -718,10 +796,20 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
         const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
         uint32_t P = num > (uint32_t)(J.na + 1) ? num : (uint32_t)(J.na + 1);  // positions pc_block writes ...
         P = P < n8 ? P : n8;                                                   // ... that dyn_comp will read
-        lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
-                                 lane, nullptr, 0, &head, pass == 0 ? 1 : 2);
+        if constexpr (PUB) {
+            if (last)
+                lms_pass<DEPTH, CH, LPC, true>(sh, A, J, a, num, P, true, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
+                                               lane, flag, 0, &head, 2);
+            else
+                lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, false, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain, lane,
+                                         nullptr, 0, &head, pass == 0 ? 1 : 2);
+        } else {
+            lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
+                                     lane, nullptr, 0, &head, pass == 0 ? 1 : 2);
+        }
     }
     store_row<LPC>(J, a, lane);
+    if constexpr (PUB) publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come
 }
 
 // <T3, L3>: mapping of the 4-tap rows, <T7, L7>: of the 8-tap rows (<4, 1> and <4, 2>; <2, 2> and <2, 4> for tiny batches)
@@ -797,17 +885,21 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
 // ---- k_search1_fused: k_lms_search1 and k_gol_count1 in one launch.  Workgroups [0, nLms) walk the five
 // mixRes passes and publish (pass << 16) + rows; the count waves of pass r follow them through plane r.
 template <int DEPTH, int T, int L>
-__global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, uint32_t cblocks, uint32_t chanBits)
+__global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_search1_fused(V1Args A, uint32_t nLms, uint32_t cblocks, uint32_t chanBits)
 {
-    __shared__ LmsShared<L> sh;
-    __shared__ uint32_t recip[17];
-    const int lane = threadIdx.x;
-    if (blockIdx.x < nLms) {
-        search1_predictor<DEPTH, T, L>(sh, A, blockIdx.x, lane, A.flags + blockIdx.x);
+    __shared__ LmsShared<L> shAll[kWavesPerWg];
+    __shared__ uint32_t recipAll[kWavesPerWg][20];
+    const Worker W = worker_id();
+    if (W.id >= nLms + 5 * cblocks) return;
+    LmsShared<L> &sh = shAll[W.slot];
+    uint32_t *recip = recipAll[W.slot];
+    const int lane = W.lane;
+    if (W.id < nLms) {
+        search1_predictor<DEPTH, T, L>(sh, A, W.id, lane, A.flags + W.id);
     } else {
         gol_table_init(recip, lane);
-        __syncthreads();
-        const uint32_t idx = blockIdx.x - nLms, r = idx / cblocks, w = idx % cblocks;
+        lds_order();
+        const uint32_t idx = W.id - nLms, r = idx / cblocks, w = idx % cblocks;
         const uint32_t chain = A.S.segBegin * 2 + w * 64u + lane;
         const uint32_t t = r * A.chainsPad + chain;
         uint32_t p, N;
@@ -828,32 +920,12 @@ __global__ __launch_bounds__(64) void k_search1_fused(V1Args A, uint32_t nLms, u
     }
 }
 
-// codec/ALACEncoder.cu:374-380: first minimum of bits1 + bits2 over mixRes 0..4
-static __global__ void k_decide1(V1Args A)
-{
-    const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t p, N;
-    if (!seg_packet(A.S, seg, p, N)) return;
-    uint32_t best = 0, minb = 1u << 31;
-    for (uint32_t r = 0; r <= (uint32_t)kMaxRes; r++) {
-        const uint32_t tot = A.bits1[r * A.chainsPad + seg * 2] + A.bits1[r * A.chainsPad + seg * 2 + 1];
-        if (tot < minb) {
-            minb = tot;
-            best = r;
-        }
-    }
-    A.recs[p].mixRes = best;
-}
-
 // search2 counts: stream = rowsel * chainsPad + chain.  Stereo: positions < P2 come from the last converge
 // pass (resB), the tail from the mixRes = 4 search pass (resA) — codec/ALACEncoder.cu:433-445.
-template <int CH>
-__global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
+template <int CH, class Need>
+__device__ __forceinline__ void count2_body(const V1Args &A, uint32_t chain, uint32_t rs, uint32_t chanBits, const uint32_t *recip,
+                                            Need &&need)
 {
-    __shared__ uint32_t recip[17];
-    gol_table_init(recip, threadIdx.x);
-    __syncthreads();
-    const uint32_t chain = A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, rs = blockIdx.y;
     const uint32_t t = rs * A.chainsPad + chain;
     uint32_t p, N;
     const bool active = seg_packet(A.S, chain / CH, p, N);
@@ -880,14 +952,61 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
         rs2.s1 = strideA;
         rs2.split = CH == 1 ? 0xffffffffu : p2hi;
         rs2.col = chain;
-        golf_stream<false>(g, n8, nMax, chanBits, recip, rs2);
+        golf_stream<false>(g, n8, nMax, chanBits, recip, rs2, need);
     } else {
         golf_stream_fn<false>(g, n8, nMax, chanBits, recip, [&](uint32_t j) {
             const int32_t b = (planeB + j * strideB)[chain], a = (planeA + j * strideA)[chain];
             return j < P2 ? b : a;
-        });
+        }, need);
     }
     if (active) A.cost2[t] = g.bits * 8 + 16 * na;  // :438, :447 / :899
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
+{
+    __shared__ uint32_t recip[17];
+    gol_table_init(recip, threadIdx.x);
+    __syncthreads();
+    count2_body<CH>(A, A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, blockIdx.y, chanBits, recip, NoWait());
+}
+
+// ---- k_search2_fused: k_lms_search2 and k_gol_count2 in one launch (latency regime).  Workgroups [0, nb3) walk the 4-tap
+// rows (64 chains each), [nb3, nPred) the 8-tap rows (32 chains each); the last of their 8 converge passes stores its rows
+// written through and publishes them tile by tile.  The remaining 2 * cblocks workgroups are the count waves (row set rs,
+// 64 chains each): they follow their producers through the P2 rows of that pass and then walk the stale tail in the mixRes = 4
+// plane of the search launch before (complete long ago).  A count that ran as its own launch only started when the slowest
+// predictor wave had finished all eight passes.
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_search2_fused(V1Args A, uint32_t nb3, uint32_t nPred, uint32_t cblocks, uint32_t chanBits)
+{
+    __shared__ union {
+        LmsShared<1> s1;
+        LmsShared<2> s2;
+    } shAll[kWavesPerWg];
+    __shared__ uint32_t recipAll[kWavesPerWg][20];
+    const Worker W = worker_id();
+    if (W.id >= nPred + 2 * cblocks) return;
+    auto &sh = shAll[W.slot];
+    uint32_t *recip = recipAll[W.slot];
+    const int lane = W.lane;
+    uint32_t *flags = A.flags2;
+    if (W.id < nb3) {
+        search2_body<DEPTH, CH, 0, 4, 1, true>(sh.s1, A, W.id, lane, flags + W.id);
+    } else if (W.id < nPred) {
+        search2_body<DEPTH, CH, 1, 4, 2, true>(sh.s2, A, W.id - nb3, lane, flags + W.id);
+    } else {
+        gol_table_init(recip, lane);
+        lds_order();
+        const uint32_t idx = W.id - nPred, rs = idx / cblocks, w = idx % cblocks;
+        RowWait wait;
+        if (rs == 0) wait.producers(flags, w, 1, nb3);
+        else wait.producers(flags, nb3 + 2 * w, 2, nPred);
+        wait.avail = 0;
+        wait.base = 0;
+        wait.ho = A.ho;
+        count2_body<CH>(A, A.S.segBegin * CH + w * 64u + (uint32_t)lane, rs, chanBits, recip, wait);
+    }
 }
 
 // numU / numV, escape estimate (codec/ALACEncoder.cu:438-461, mono :899-915), header coefficients
@@ -959,32 +1078,107 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
 // compiler drops everything that only feeds it), then code [splitAt, N) into a second slot.  A run that is open at the
 // split is closed by the second wave, which has counted its zeros from the start.  k_splice_split appends the second
 // string to the first afterwards.  A chained file is two chains: its packet position is as long as ONE coder chain.
-template <int DEPTH, int CH, int T = 4, int L = 2, bool SPLIT = false>
-__global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits, uint32_t nCoder = 0)
+// FOLD: the launch also does what k_decide2 and k_finalize do (two launches and their boundaries less per packet position):
+// every wave evaluates numU / numV / the escape estimate of its packets itself from the search's cost words (decide_packet);
+// the predictor lanes leave the header fields in the record (tap count, the row's coefficients BEFORE the pass adapts them,
+// sample count), the coder lanes — the only ones that know the coded bits — the final escape decision, the total bits and
+// the packet's byte size.  No lane reads a record field another lane of the launch writes.
+template <int DEPTH, int CH, int T = 4, int L = 2, bool SPLIT = false, bool FOLD = false>
+__global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits, uint32_t nCoder, uint32_t nWorkers)
 {
-    __shared__ LmsShared<L> sh;
-    __shared__ uint32_t recip[17];
-    const int lane = threadIdx.x;
-    if (blockIdx.x < nLms) {
+    static_assert(!(FOLD && SPLIT), "the folded decision is built for the plain two-lane launch");
+    __shared__ LmsShared<L> shAll[kWavesPerWg];
+    __shared__ uint32_t recipAll[kWavesPerWg][20];
+    const Worker W = worker_id();
+    if (W.id >= nWorkers) return;
+    LmsShared<L> &sh = shAll[W.slot];
+    uint32_t *recip = recipAll[W.slot];
+    const int lane = W.lane;
+    // Roles.  A coder wave issues one scattered store per symbol (64 lanes, 64 lines): four of them on one CU queue up in that
+    // CU's memory pipeline (measured: 2.06 M cycles per coder wave against 1.69 M, +22 % on the launch, when the workers were
+    // numbered predictors first and a workgroup was four coders).  So the roles are dealt P P C P P C ... (L = 2 predictor
+    // waves feed one coder wave; P P P P C for L = 4): worker (L + 1) t + r is predictor L t + r for r < L and coder t for
+    // r = L — at most two coder waves per workgroup, predictors beside them.
+    // (SPLIT, the tiny-batch form, has three roles and a handful of waves: predictors first, as before.)
+    uint32_t wid = W.id;     // role-relative index: predictor wave wid, resp. coder wave wid - nLms
+    if constexpr (!SPLIT) {
+        const uint32_t t = W.id / (L + 1), r = W.id % (L + 1);
+        wid = r < (uint32_t)L ? (uint32_t)L * t + r : nLms + t;
+        if (r < (uint32_t)L && wid >= nLms) return;
+    }
+    // option "debug_waves": where and when every wave of the launch ran (HW_ID, XCC_ID, s_memtime at entry and exit), 8 dwords
+    // per workgroup in A.dbg — tools/wave_map.py
+    struct WaveStamp {
+        uint32_t *p;
+        __device__ __forceinline__ WaveStamp(uint32_t *dbg, int lane) : p(dbg ? dbg + 8ull * (blockIdx.x * (uint32_t)kWavesPerWg + (threadIdx.x >> 6)) : nullptr)
+        {
+            if (p && lane == 0) {
+                const uint64_t t = __builtin_amdgcn_s_memtime();
+                p[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+                p[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+                p[2] = (uint32_t)t;
+                p[3] = (uint32_t)(t >> 32);
+            }
+        }
+        __device__ __forceinline__ void done(int lane)
+        {
+            if (p && lane == 0) {
+                const uint64_t t = __builtin_amdgcn_s_memtime();
+                p[4] = (uint32_t)t;
+                p[5] = (uint32_t)(t >> 32);
+                p[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            }
+        }
+    } stamp(A.dbg, lane);
+    if (wid < nLms) {
         ChainJob J;
-        const uint32_t chain = A.S.segBegin * CH + blockIdx.x * (64u / L) + lane / L;
+        const uint32_t chain = A.S.segBegin * CH + wid * (64u / L) + lane / L;
         J.seg = chain / CH;
         J.ch = chain % CH;
         J.active = seg_packet(A.S, J.seg, J.p, J.N);
         J.na = 4;
         int best = 0;
         const uint32_t N = J.N;
+        const bool have = J.active;
         if (J.active) {
-            const PacketRec *rec = A.recs + J.p;
-            J.na = rec->c[J.ch].num;
-            best = (int)rec->mixRes;
-            if (rec->escape) J.active = false;
+            if constexpr (FOLD) {
+                const PacketDecision D = decide_packet<DEPTH, CH>(A, J.seg, N);
+                J.na = (int)D.num[J.ch];
+                best = CH == 2 ? (int)A.recs[J.p].mixRes : 0;  // written by the converge launch (search2_body)
+                if (D.escape) J.active = false;
+            } else {
+                const PacketRec *rec = A.recs + J.p;
+                J.na = rec->c[J.ch].num;
+                best = (int)rec->mixRes;
+                if (rec->escape) J.active = false;
+            }
         }
         J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
         int32_t a[T];
         load_row<L>(J, a, lane);
+        if constexpr (FOLD) {
+            if (have) {
+                // header fields (codec/ALACEncoder.cu:477-485: the coefficients go into the header before the final pass)
+                PacketRec *rec = A.recs + J.p;
+                const int h = lane & (L - 1);
+#pragma unroll
+                for (int i = 0; i < T; i++)
+                    if (T * h + i < 8) rec->c[J.ch].coefs[T * h + i] = (T * h + i < J.na) ? (int16_t)a[i] : (int16_t)0;
+                if (h == 0) {
+                    rec->c[J.ch].num = (uint16_t)J.na;
+                    if (J.ch == 0) {
+                        rec->numSamples = N;
+                        if (CH == 1) {
+                            rec->c[1].num = 0;
+                            rec->c[1].bits = 0;
+                            rec->mixRes = 0;
+                        }
+                    }
+                }
+            }
+        }
         lms_setup<L>(sh, J, best, lane);
-        uint32_t *flag = A.flagsF + blockIdx.x;
+        uint32_t *flag = A.flagsF + wid;
         lms_pass<DEPTH, CH, L, true, true>(sh, A, J, a, N, N, true, A.resC, A.chainsPad, chain, lane, flag);
         store_row<L>(J, a, lane);
         if (A.rowReady) {
@@ -996,10 +1190,11 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
                 __hip_atomic_store(A.rowReady + chain, A.S.pos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come (also covers inactive waves)
+        stamp.done(lane);
     } else {
         gol_table_init(recip, lane);
-        __syncthreads();
-        const uint32_t cb = blockIdx.x - nLms;
+        lds_order();
+        const uint32_t cb = wid - nLms;
         const bool second = SPLIT && cb >= nCoder;
         const uint32_t w = second ? cb - nCoder : cb;
         const uint32_t chain = A.S.segBegin * CH + w * 64u + lane;
@@ -1007,7 +1202,14 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
         bool active = seg_packet(A.S, chain / CH, p, N);
         const bool have = active;
         PacketRec *rec = A.recs + p;
-        if (active && rec->escape) active = false;
+        PacketDecision D;
+        D.num[0] = D.num[1] = D.escape = 0;
+        if constexpr (FOLD) {
+            if (have) D = decide_packet<DEPTH, CH>(A, chain / CH, N);
+            if (D.escape) active = false;
+        } else {
+            if (active && rec->escape) active = false;
+        }
         const uint32_t c = chain % CH;
         const uint32_t n = active ? N : 0;
         const int32_t *plane = A.resC;
@@ -1025,7 +1227,29 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
             golf_open(g, slot, A.wcap);
             golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
             golf_flush<true>(g);
-            if (active) rec->c[c].bits = golf_written_bits(g, slot);
+            const uint32_t bits = active ? golf_written_bits(g, slot) : 0u;
+            if (active) rec->c[c].bits = bits;
+            if constexpr (FOLD) {
+                // k_finalize: packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543,
+                // :952-958).  A stereo packet's channels sit in adjacent lanes (chain = 2 * segment + channel, 64 chains per wave).
+                const uint32_t other = CH == 2 ? (uint32_t)__shfl_xor((int)bits, 1) : 0u;
+                if (have && c == 0) {
+                    constexpr uint32_t SHB = bytes_shifted(DEPTH);
+                    const uint32_t partial = (N != A.S.frameSize);
+                    const uint32_t escapeBits = N * DEPTH * CH + (partial ? 32 : 0) + 16;
+                    bool esc = D.escape != 0;
+                    uint32_t body = 0;
+                    if (!esc) {
+                        body = 12 + 4 + (partial ? 32 : 0) + 16 + N * (SHB * 8) * CH + (16 + 16 * D.num[0] + bits);
+                        if (CH == 2) body += 16 + 16 * D.num[1] + other;
+                        if (body >= escapeBits) esc = true;
+                    }
+                    if (esc) body = 12 + 4 + (partial ? 32 : 0) + N * DEPTH * CH;
+                    rec->escape = esc ? 1u : 0u;
+                    rec->totalBits = 7 + body + 3;
+                    A.packetBytes[p] = (7 + body + 3 + 7) / 8;
+                }
+            }
         } else {
             const uint32_t a = A.splitAt;
             const uint32_t nA = min(n, a), nB = n - nA;
@@ -1051,6 +1275,7 @@ __global__ __launch_bounds__(64) void k_final_fused(V1Args A, uint32_t nLms, uin
                 if (have) A.bitsB[slotIdx] = (active && nB) ? golf_written_bits(g, slot) : 0u;
             }
         }
+        stamp.done(lane);
     }
 }
 
@@ -1147,7 +1372,7 @@ __global__ __launch_bounds__(64, 2) void k_search1_lane(V1Args A, uint32_t chanB
     J.na = 8;
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + 16;
     int32_t a[8];
-    load_row<1, 8>(J, a, lane);
+    load_row<1, 8>(J, a, lane, A.virgin != 0);
     const uint32_t n8 = J.active ? J.N / 8 : 0;
     const uint32_t nMax = wave_max(n8), nMin = wave_min_u32(n8);  // a lane without residuals puts the wave on the checked path
     for (int r = 0; r <= kMaxRes; r++) {
@@ -1179,8 +1404,9 @@ __device__ __forceinline__ void search2_lane_body(LmsShared<1> &sh, const uint32
     J.na = T;
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + RS * 16;
     int32_t a[T];
-    load_row<1, T>(J, a, lane);
-    const int best = (CH == 2 && J.active) ? (int)A.recs[J.p].mixRes : 0;
+    load_row<1, T>(J, a, lane, A.virgin != 0 && (RS == 0 || CH == 1));
+    const int best = (CH == 2 && J.active) ? pick_mixres(A, J.seg) : 0;
+    if (CH == 2 && RS == 1 && J.active && J.ch == 0) A.recs[J.p].mixRes = (uint32_t)best;
     lms_setup<1>(sh, J, best, lane);
     const uint32_t n8 = J.N / 8, n32 = J.N / 32;
     uint32_t P2 = n8;  // residuals of the last converge pass that the count reads (k_gol_count2)
@@ -1507,6 +1733,7 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
     // latency of one serial chain per lane and leave most SIMDs idle, so sub-batch h+1 starts its predictor
     // kernels as soon as sub-batch h has finished its first one and the two kinds of kernel overlap.
     const uint32_t H = v1_sub_batches(nsegAll, vs.numSub, CH);
+    bool latFoldAny = false;
     uint32_t per = ((nsegAll + H - 1) / H + 63) & ~63u;         // whole waves per sub-batch
     if (H > 1) (void)hipEventRecord(vs.fork, st);
     for (uint32_t h = 0; h < H; h++) {
@@ -1566,22 +1793,37 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             // search) — ~44 instead of ~62 instructions per wave step on every serial chain of the packet position.
             const bool narrow = A.narrow != 0 && fuse;
             const uint32_t nLms16 = (nseg * CH + 15) / 16;
+            A.virgin = firstPos ? A0.virgin : 0u;
+            // Latency regime, two lanes per chain: the small launches between the big ones are folded away ("fold" = 0 keeps
+            // them): the converge passes and their counts share a launch (k_search2_fused), the final launch decides numU / numV /
+            // escape and the packet sizes itself (k_final_fused<.., FOLD>), and ONE memset clears the progress words of all three
+            // producer/consumer launches of the position.
+            // (experiments: bit 0 of "fold" = the converge launch, bit 1 = the final launch, bit 2 = one memset for all flag words)
+            const bool foldOk = fuse && !narrow;
+            const bool latFold2 = foldOk && (opt.fold & 1), latFold = foldOk && (opt.fold & 2), oneMemset = foldOk && (opt.fold & 4);
+            latFoldAny = latFoldAny || latFold;
+            if (foldOk) {
+                A.flags2 = A0.flags + ((A0.chainsPad / 32 + 4) & ~3u);   // behind the (at most chains / 32) words of the search launch
+                A.flagsF = A0.ovFlagsF;                                  // the second set
+                A.foldDecide = latFold ? 1 : 0;
+                if (oneMemset) (void)hipMemsetAsync(A.flags, 0, (size_t)2 * (A0.chainsPad / 8 + 16) * 4, sp);
+            }
             if constexpr (CH == 2) {
                 const bool wide = A.wide81 != 0;
                 const uint32_t nLms1 = wide ? cblocks : nLms;
                 // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
                 if (fuse && narrow && A.S.frameSize / 8 < 65536u) {
                     (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
-                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 2, 4>), dim3(nLms16 + 5 * cblocks), dim3(64), 0, sp, A, nLms16, cblocks,
+                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 2, 4>), dim3((nLms16 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms16, cblocks,
                                        chanBits);
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else if (fuse && A.S.frameSize / 8 < 65536u) {
-                    (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
+                    if (!oneMemset) (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
                     if (wide)
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3((nLms1 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms1,
                                            cblocks, chanBits);
                     else
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3(nLms1 + 5 * cblocks), dim3(64), 0, sp, A, nLms1,
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3((nLms1 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms1,
                                            cblocks, chanBits);
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else if (thru && wide && opt.searchFused) {
@@ -1598,14 +1840,17 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
                     hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sp, A, chanBits);
                 }
-                hipLaunchKernelGGL(k_decide1, dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             } else if (e) {
                 (void)hipEventRecord(e[kStageGol1], sp);
             }
             if (overlap && pos > 0) (void)hipStreamWaitEvent(sp, vs.join[(pos - 1) & 1], 0);  // final pass of pos - 1
             if (e) (void)hipEventRecord(e[kStageLms2], sp);
             const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
-            if (narrow)
+            if (latFold2) {
+                if (!oneMemset) (void)hipMemsetAsync(A.flags2, 0, ((size_t)(nb3 + nb7) * 4 + 15) & ~(size_t)15, sp);
+                hipLaunchKernelGGL((k_search2_fused<DEPTH, CH>), dim3((nb3 + nb7 + 2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nb3, nb3 + nb7, cblocks,
+                                   chanBits);
+            } else if (narrow)
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
             else if (thru && opt.searchFused)  // as below, and every lane counts its own residuals
                 hipLaunchKernelGGL((k_search2_lane<DEPTH, CH>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3, chanBits);
@@ -1615,9 +1860,9 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
             if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
             if (e) (void)hipEventRecord(e[kStageGol2], sp);
-            if (!(thru && opt.searchFused) || narrow)
+            if (!latFold2 && (!(thru && opt.searchFused) || narrow))
                 hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
-            hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
+            if (!latFold) hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             if (overlap) (void)hipEventRecord(vs.stagger[pos & 1], sp);
             if (e) (void)hipEventRecord(e[kStageLms3], sp);
             if (thru) {
@@ -1660,17 +1905,23 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             } else if (narrow) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
                 if (A.bitWordsB && A.splitAt >= 48) {
-                    hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4, true>), dim3(nLms16 + 2 * cblocks), dim3(64), 0, sp, A, nLms16,
-                                       chanBits, cblocks);
+                    hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4, true>), dim3((nLms16 + 2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms16,
+                                       chanBits, cblocks, nLms16 + 2 * cblocks);
                     hipLaunchKernelGGL(k_splice_split<CH>, dim3(nseg * CH), dim3(64), 0, sp, A);
                 } else {
-                    hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3(nLms16 + cblocks), dim3(64), 0, sp, A, nLms16, chanBits,
-                                       0u);
+                    hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3((5 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
+                                       dim3(64 * kWavesPerWg), 0, sp, A, nLms16, chanBits, 0u, 5 * cblocks);
                 }
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
+            } else if (latFold) {
+                if (!oneMemset) (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 4, 2, false, true>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
+                                   dim3(64 * kWavesPerWg), (size_t)opt.ldsPad, sp, A, nLms, chanBits, 0u, 3 * cblocks);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else if (fuse) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
-                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3(nLms + cblocks), dim3(64), 0, sp, A, nLms, chanBits, 0u);
+                hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg),
+                                   (size_t)opt.ldsPad, sp, A, nLms, chanBits, 0u, 3 * cblocks);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else {
                 hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sp, A);
@@ -1691,8 +1942,9 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
     // sizes, scan, pack: once, on the caller's stream; events live in the slot after the last sub-batch
     hipEvent_t *evt = ev ? ev + (size_t)vs.maxSub * (kNumStages + 1) : nullptr;
     if (evt) (void)hipEventRecord(evt[kStageScan], st);
-    hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A0.recs, A0.packetBytes,
-                       numPackets, A0.S.frameSize);
+    if (!latFoldAny)  // (the folded final launches have written the packet sizes)
+        hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A0.recs, A0.packetBytes,
+                           numPackets, A0.S.frameSize);
     launch_scan_pack(DEPTH, CH, A0.packetBytes, pa, numPackets, st, evt, false);
 }
 

@@ -41,7 +41,13 @@ struct V1Args {
     uint32_t wcap;
     uint32_t dumpSlot;     // channel slot index (2 * numPackets) no packet owns: bit words of lanes without a packet
     uint32_t *packetBytes;
-    uint32_t *flags;       // producer progress words of the fused final kernel (zeroed per call)
+    uint32_t *flags;       // producer progress words of the fused search launch (zeroed per call)
+    uint32_t *flags2;      // ... of the fused converge launch (k_search2_fused): behind those of the search launch
+    uint32_t *dbg;         // option "debug_waves": 8 dwords per workgroup of the fused final launch (null: off)
+    uint32_t virgin;       // 1: the coefficient rows have never been written (first packet position, state in the workspace):
+                           // load_row takes init_coefs instead of reading them
+    uint32_t foldDecide;   // 1: k_final_fused<.., FOLD> decides numU / numV / escape and the packet size itself (no k_decide2,
+                           // no k_finalize launch)
     uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
     uint32_t idleFast;     // 1: lanes without work do not force the checked paths (latency regime, see launcher)
     HandoffCtl ho;         // error word / spin bound / test switch of the in-launch hand-offs

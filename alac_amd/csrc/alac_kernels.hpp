@@ -101,6 +101,13 @@ struct AlacOptions {
     int32_t decPubMask = 31;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols
     int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
     int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
+    int32_t initState = 0;     // "init_state"   ALAC_HIP_INIT_STATE  1: k_init_state writes the workspace rows even where the kernels take
+                               //                                     init_coefs as constants (experiments)
+    int32_t debugWaves = 0;    // "debug_waves"  wave placement / timing stamps of the fused final launch into the workspace (tools/wave_map.py)
+    int32_t ldsPad = 0;        // "lds_pad"      ALAC_HIP_LDS_PAD     dynamic LDS bytes added to the single-wave workgroups of the fused final
+                               //                                     launch (caps the workgroups a CU takes: experiments)
+    int32_t fold = 6;          // "fold"         ALAC_HIP_FOLD        latency regime: converge passes || counts in one launch, decision and
+                               //                                     packet sizes inside the final launch, no k_init_state / k_decide* / k_finalize
     int32_t searchFused = 1;   // "search_fused" ALAC_HIP_SEARCH_FUSED throughput regime: search passes + their bit counts in one lane
     int32_t classFused = 1;    // "class_fused"  ALAC_HIP_CLASS_FUSED throughput regime: final predictor + coder of a chain in one lane
     int32_t persist = -1;      // "persist"      ALAC_HIP_PERSIST     chained tiny batches: one persistent launch per batch
@@ -114,6 +121,7 @@ struct V1Buffers {
     HandoffCtl ho;
     int16_t *state;        // [segments][64] working coefficient rows (caller's d_state or workspace)
     bool stateInitialised; // rows already hold the caller's initial state
+    bool stateInternal;    // the rows live in the workspace: nobody reads entries the pipeline does not write
     int32_t *resA, *resB, *resC;
     uint32_t *bits1, *cost2;
     uint32_t *flags;       // progress words of the fused kernels, one per predictor wave (up to chainsPad / 8 + 16)

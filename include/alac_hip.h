@@ -78,6 +78,10 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  * Every setting produces the same bytes; only the kernels that run differ.  Unknown key -> kALAC_ParamError. */
 int32_t alac_hip_set_option(alac_hip_ctx *ctx, const char *key, int32_t value);
 int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value);
+/* Diagnostics: with option "debug_waves" = 1 the fused final launch of alac_hip_encode leaves 8 dwords per workgroup at this
+ * byte offset of the caller's workspace (HW_ID, XCC_ID, s_memtime at entry, at exit, HW_ID at exit, 0): where and when every
+ * wave ran (tools/wave_map.py).  Batches above 4096 chains only (below, the words are the row-ready flags of chained files). */
+uint64_t alac_hip_debug_waves_offset(const alac_hip_format *fmt, uint32_t num_packets, uint32_t num_segments);
 /* The encode regime this context would pick for a batch of num_segments independent segments of this format (a static
  * string): "throughput" (separate launches, 64 chains per wave), "latency" (producer/consumer launches, two lanes per
  * chain), "tiny" (four lanes per chain: chained files) or "lane" (first-generation kernel).  For reporting. */

@@ -20,6 +20,8 @@ VARIANTS = {
     "idle-checked": {"idlefast": 0},
     "release-fence": {"pubfence": 1},
     "two-lane-latency-regime": {"narrow": 0},
+    "two-lane-latency-regime-unfolded": {"narrow": 0, "fold": 0},
+    "throughput-regime-separate-stages": {"thru": 1, "class_fused": 0, "search_fused": 0},
     "throughput-regime": {"thru": 1},
     "throughput-regime-sub-batches": {"thru": 1, "subbatch": 2},
     "positions-not-overlapped": {"overlap_pos": 0},

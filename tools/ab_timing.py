@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--passes", type=int, default=10)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--state", action="store_true", help="pass a caller-owned coefficient state (k_init_state runs)")
     a = ap.parse_args()
     fmt = alac_amd.make_format(4096, a.depth, 2, 44100)
     B = a.packets
@@ -37,6 +38,7 @@ def main():
     d_pcm = ctx.synth_pcm(0, B, fmt)
     sets = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in s.split(",") if kv) for s in a.sets]
     bufs = [ctx.encode_buffers(fmt, B) for _ in sets]
+    kw = {"state": torch.zeros((B, 64), dtype=torch.int16, device="cuda")} if a.state else {}
     times = [[] for _ in sets]
     stage = [None] * len(sets)
     cookie = ctx.magic_cookie(fmt)
@@ -48,7 +50,7 @@ def main():
                 with ctx.options(**opts):
                     if a.decode:
                         if r == 0:
-                            ctx.encode(fmt, d_pcm, B, bufs=bufs[i])
+                            ctx.encode(fmt, d_pcm, B, bufs=bufs[i], **kw)
                         ctx.decode(cookie, bufs[i]["out"], bufs[i]["offsets"], B, out=d_out)
                         ctx.synchronize()
                         t0 = time.perf_counter()
@@ -60,13 +62,13 @@ def main():
                             ok = bool(torch.equal(d_out[0], d_pcm)) and int(d_out[2].abs().sum()) == 0
                             print(f"set {i} {opts}: decode round trip exact: {ok}")
                     else:
-                        ctx.encode(fmt, d_pcm, B, bufs=bufs[i])
+                        ctx.encode(fmt, d_pcm, B, bufs=bufs[i], **kw)
                         ctx.synchronize()
                         if r == a.rounds:
                             ctx.profile_begin(a.passes)
                         t0 = time.perf_counter()
                         for _ in range(a.passes):
-                            ctx.encode(fmt, d_pcm, B, bufs=bufs[i])
+                            ctx.encode(fmt, d_pcm, B, bufs=bufs[i], **kw)
                         ctx.synchronize()
                         dt = (time.perf_counter() - t0) / a.passes
                         if r == a.rounds:
