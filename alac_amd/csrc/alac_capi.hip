@@ -72,6 +72,7 @@ AlacOptions alac_options_from_env()
     o.searchFused = env_int("ALAC_HIP_SEARCH_FUSED", o.searchFused) != 0;
     o.fold = env_int("ALAC_HIP_FOLD", o.fold);
     o.ldsPad = env_int("ALAC_HIP_LDS_PAD", o.ldsPad);
+    o.countWalk = env_int("ALAC_HIP_COUNT_WALK", o.countWalk);
     o.initState = env_int("ALAC_HIP_INIT_STATE", o.initState) != 0;
     return o;
 }
@@ -90,7 +91,7 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
         {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
         {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"lds_pad", &AlacOptions::ldsPad},
-        {"debug_waves", &AlacOptions::debugWaves},
+        {"debug_waves", &AlacOptions::debugWaves}, {"count_walk", &AlacOptions::countWalk},
         {"init_state", &AlacOptions::initState},
     };
     for (const auto &t : table)

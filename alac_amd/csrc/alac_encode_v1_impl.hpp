@@ -828,6 +828,27 @@ __global__ __launch_bounds__(64, WAVES) void k_lms_search2(V1Args A, uint32_t nb
         search2_body<DEPTH, CH, 1, T7, L7>(sh.s2, A, blockIdx.x - nb3, threadIdx.x);
 }
 
+// The latency regime's form of the above as a launch of workers (4-wave workgroups, see worker_id): roles dealt A B B — worker
+// 3 t is the 4-tap wave t (64 chains, <4, 1>), workers 3 t + 1, 3 t + 2 the 8-tap waves 2 t, 2 t + 1 (32 chains each, <4, 2>):
+// nb3 + nb7 <= 1024 waves get a SIMD each by construction, whatever the launches before left in the CUs' wave allocators.
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_lms_search2_w(V1Args A, uint32_t nb3, uint32_t nb7)
+{
+    __shared__ union {
+        LmsShared<1> s1;
+        LmsShared<2> s2;
+    } shAll[kWavesPerWg];
+    const Worker W = worker_id();
+    auto &sh = shAll[W.slot];
+    const uint32_t t = W.id / 3, r = W.id % 3;
+    if (r == 0) {
+        if (t < nb3) search2_body<DEPTH, CH, 0, 4, 1>(sh.s1, A, t, W.lane);
+    } else {
+        const uint32_t b = 2 * t + r - 1;
+        if (b < nb7) search2_body<DEPTH, CH, 1, 4, 2>(sh.s2, A, b, W.lane);
+    }
+}
+
 // ---- k_lms_final: final pass with the chosen row (codec/ALACEncoder.cu:505-532, :941)
 template <int DEPTH, int CH>
 __global__ __launch_bounds__(64) void k_lms_final(V1Args A)
@@ -884,16 +905,50 @@ __global__ __launch_bounds__(64) void k_gol_count1(V1Args A, uint32_t chanBits)
 
 // ---- k_search1_fused: k_lms_search1 and k_gol_count1 in one launch.  Workgroups [0, nLms) walk the five
 // mixRes passes and publish (pass << 16) + rows; the count waves of pass r follow them through plane r.
-template <int DEPTH, int T, int L>
+// WALK: ONE count wave per 64 chains that walks the five planes in turn behind its L producers, roles dealt P .. P C like the
+// final launch: (L + 1) cblocks workers instead of nLms + 5 cblocks — at 10 000 packets 938 instead of 2190, so that no
+// predictor wave (the launch's serial chain) ever shares its SIMD with a count wave.
+template <int DEPTH, int T, int L, bool WALK = false>
 __global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_search1_fused(V1Args A, uint32_t nLms, uint32_t cblocks, uint32_t chanBits)
 {
     __shared__ LmsShared<L> shAll[kWavesPerWg];
     __shared__ uint32_t recipAll[kWavesPerWg][20];
     const Worker W = worker_id();
-    if (W.id >= nLms + 5 * cblocks) return;
     LmsShared<L> &sh = shAll[W.slot];
     uint32_t *recip = recipAll[W.slot];
     const int lane = W.lane;
+    if constexpr (WALK) {
+        if (W.id >= (uint32_t)(L + 1) * cblocks) return;
+        const uint32_t t = W.id / (L + 1), r0 = W.id % (L + 1);
+        if (r0 < (uint32_t)L) {
+            const uint32_t pw = (uint32_t)L * t + r0;
+            if (pw < nLms) search1_predictor<DEPTH, T, L>(sh, A, pw, lane, A.flags + pw);
+            return;
+        }
+        gol_table_init(recip, lane);
+        lds_order();
+        const uint32_t w = t;
+        const uint32_t chain = A.S.segBegin * 2 + w * 64u + lane;
+        uint32_t p, N;
+        const bool active = seg_packet(A.S, chain >> 1, p, N);
+        const uint32_t n8 = active ? N / 8 : 0;
+        const uint64_t stride = 5ull * A.chainsPad;
+        RowWait wait;
+        wait.producers(A.flags, L * w, L, nLms);
+        wait.avail = 0;
+        wait.ho = A.ho;
+        const uint32_t nMax = wave_max(n8);
+#pragma unroll 1
+        for (uint32_t r = 0; r <= (uint32_t)kMaxRes; r++) {
+            GolF g;
+            golf_reset(g);
+            wait.base = r << 16;
+            golf_stream<false>(g, n8, nMax, chanBits, recip, one_plane(A.resA + (uint64_t)r * A.chainsPad, stride, chain), wait);
+            if (active) A.bits1[r * A.chainsPad + chain] = g.bits;
+        }
+        return;
+    }
+    if (W.id >= nLms + 5 * cblocks) return;
     if (W.id < nLms) {
         search1_predictor<DEPTH, T, L>(sh, A, W.id, lane, A.flags + W.id);
     } else {
@@ -969,6 +1024,19 @@ __global__ __launch_bounds__(64) void k_gol_count2(V1Args A, uint32_t chanBits)
     gol_table_init(recip, threadIdx.x);
     __syncthreads();
     count2_body<CH>(A, A.S.segBegin * CH + blockIdx.x * 64u + threadIdx.x, blockIdx.y, chanBits, recip, NoWait());
+}
+
+// k_gol_count2 as a launch of workers: worker w counts row set w / cblocks of chains (w % cblocks) * 64 ...
+template <int CH>
+__global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_gol_count2_w(V1Args A, uint32_t cblocks, uint32_t chanBits)
+{
+    __shared__ uint32_t recipAll[kWavesPerWg][20];
+    const Worker W = worker_id();
+    if (W.id >= 2 * cblocks) return;
+    uint32_t *recip = recipAll[W.slot];
+    gol_table_init(recip, W.lane);
+    lds_order();
+    count2_body<CH>(A, A.S.segBegin * CH + (W.id % cblocks) * 64u + (uint32_t)W.lane, W.id / cblocks, chanBits, recip, NoWait());
 }
 
 // ---- k_search2_fused: k_lms_search2 and k_gol_count2 in one launch (latency regime).  Workgroups [0, nb3) walk the 4-tap
@@ -1083,7 +1151,7 @@ __global__ __launch_bounds__(64) void k_gol_final(V1Args A, uint32_t chanBits)
 // the predictor lanes leave the header fields in the record (tap count, the row's coefficients BEFORE the pass adapts them,
 // sample count), the coder lanes — the only ones that know the coded bits — the final escape decision, the total bits and
 // the packet's byte size.  No lane reads a record field another lane of the launch writes.
-template <int DEPTH, int CH, int T = 4, int L = 2, bool SPLIT = false, bool FOLD = false>
+template <int DEPTH, int CH, int T = 4, int L = 2, bool SPLIT = false, bool FOLD = false, bool LAZY = false>
 __global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_final_fused(V1Args A, uint32_t nLms, uint32_t chanBits, uint32_t nCoder, uint32_t nWorkers)
 {
     static_assert(!(FOLD && SPLIT), "the folded decision is built for the plain two-lane launch");
@@ -1225,9 +1293,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_final_fused(V1Args A, u
         if constexpr (!SPLIT) {
             uint32_t *slot = A.bitWords + slotIdx * A.wcap;
             golf_open(g, slot, A.wcap);
-            golf_stream<true, true>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait, A.idleFast != 0);
-            golf_flush<true>(g);
-            const uint32_t bits = active ? golf_written_bits(g, slot) : 0u;
+            golf_stream<true, true, RowWait &, LAZY>(g, n, wave_max(n), chanBits, recip, one_plane(plane, stride, chain), wait,
+                                                     A.idleFast != 0);
+            golf_flush<true, LAZY>(g);
+            const uint32_t bits = active ? golf_written_bits<LAZY>(g, slot) : 0u;
             if (active) rec->c[c].bits = bits;
             if constexpr (FOLD) {
                 // k_finalize: packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543,
@@ -1822,6 +1891,9 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                     if (wide)
                         hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3((nLms1 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms1,
                                            cblocks, chanBits);
+                    else if (opt.countWalk)
+                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2, true>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
+                                           dim3(64 * kWavesPerWg), 0, sp, A, nLms1, cblocks, chanBits);
                     else
                         hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3((nLms1 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms1,
                                            cblocks, chanBits);
@@ -1856,12 +1928,20 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 hipLaunchKernelGGL((k_search2_lane<DEPTH, CH>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3, chanBits);
             else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
+            else if (fuse)  // latency regime: workers (one wave per SIMD by construction)
+                hipLaunchKernelGGL((k_lms_search2_w<DEPTH, CH>), dim3((3 * nb3 + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
+                                   nb3, nb7);
             else
                 hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
             if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
             if (e) (void)hipEventRecord(e[kStageGol2], sp);
-            if (!latFold2 && (!(thru && opt.searchFused) || narrow))
-                hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+            if (!latFold2 && (!(thru && opt.searchFused) || narrow)) {
+                if (fuse)
+                    hipLaunchKernelGGL(k_gol_count2_w<CH>, dim3((2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
+                                       cblocks, chanBits);
+                else
+                    hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+            }
             if (!latFold) hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             if (overlap) (void)hipEventRecord(vs.stagger[pos & 1], sp);
             if (e) (void)hipEventRecord(e[kStageLms3], sp);
@@ -1915,6 +1995,9 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else if (latFold) {
                 if (!oneMemset) (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
+                // (LAZY = true, the throughput regime's "store completed words only, four at a time", was measured here in round 3
+                // with the interleaved roles: coder waves 2.20 M instead of 1.70 M cycles, launch 0.95 instead of 0.75 ms — the
+                // queue's selects and branch cost a lone wave more than the scattered stores it saves)
                 hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 4, 2, false, true>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
                                    dim3(64 * kWavesPerWg), (size_t)opt.ldsPad, sp, A, nLms, chanBits, 0u, 3 * cblocks);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);

@@ -103,6 +103,7 @@ struct AlacOptions {
     int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
     int32_t initState = 0;     // "init_state"   ALAC_HIP_INIT_STATE  1: k_init_state writes the workspace rows even where the kernels take
                                //                                     init_coefs as constants (experiments)
+    int32_t countWalk = 1;     // "count_walk"   ALAC_HIP_COUNT_WALK  latency regime, mixRes search: one count wave per 64 chains walks the five planes
     int32_t debugWaves = 0;    // "debug_waves"  wave placement / timing stamps of the fused final launch into the workspace (tools/wave_map.py)
     int32_t ldsPad = 0;        // "lds_pad"      ALAC_HIP_LDS_PAD     dynamic LDS bytes added to the single-wave workgroups of the fused final
                                //                                     launch (caps the workgroups a CU takes: experiments)
