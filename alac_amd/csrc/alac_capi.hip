@@ -135,6 +135,19 @@ HandoffCtl handoff_ctl(const alac_hip_ctx *ctx)
     return h;
 }
 
+// the context's second stream + fork / join events (mono elements beside stereo ones in the > 2-channel encoder; buffer clears
+// beside the staging kernels in the decoder), created on first use
+bool ensure_second_stream(alac_hip_ctx *ctx)
+{
+    if (ctx->mcReady) return true;
+    if (hipStreamCreateWithFlags(&ctx->mcStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->mcFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->mcJoin, hipEventDisableTiming) != hipSuccess)
+        return false;
+    ctx->mcReady = true;
+    return true;
+}
+
 // after the stream has been synchronised: did a consumer of an in-launch hand-off give up?
 int32_t check_handoff(alac_hip_ctx *ctx)
 {
@@ -546,13 +559,7 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
     // the latency of one wave, not by the machine)
     const bool both = M.g[0].count && M.g[1].count;
     bool side = both && sub_batches_requested(ctx) <= 1;
-    if (side && !ctx->mcReady) {
-        if (hipStreamCreateWithFlags(&ctx->mcStream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->mcFork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->mcJoin, hipEventDisableTiming) != hipSuccess)
-            return fail(ctx, ALAC_HIP_MemFullError, "creating the second stream");
-        ctx->mcReady = true;
-    }
+    if (side && !ensure_second_stream(ctx)) return fail(ctx, ALAC_HIP_MemFullError, "creating the second stream");
     if (side) {
         (void)hipEventRecord(ctx->mcFork, mainStream);
         (void)hipStreamWaitEvent(ctx->mcStream, ctx->mcFork, 0);
@@ -933,11 +940,15 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess && mismatch) e = launch_decode(da, ctx->stream);
     } else {
-        e = launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream);
+        // (the plane / progress clears on the context's second stream beside the staging and header kernels were measured in
+        // round 3: 1.978 against 1.952 ms per 10 000 packets — the two cross-stream waits cost more than the 45 us of clears
+        // they hide; launch_decode_v1 keeps the parameters)
+        const bool side = false;
         // A mono / stereo stream whose packets carry another element sequence (two SCEs for two channels, fill in
-        // front of ...: status -4 from the fast pipeline) is decoded again by the lane decoder, which follows whatever
-        // the packets carry.  No host round trip: its kernels are gated on the device-side count of such packets.
-        if (e == hipSuccess) e = launch_count_status(da.statusOut, num_packets, -4, (uint32_t *)(ws + L.mismatch), ctx->stream);
+        // front of ...: status -4 from the fast pipeline, counted by its header kernel) is decoded again by the lane decoder,
+        // which follows whatever the packets carry.  No host round trip: its kernels are gated on that device-side count.
+        e = launch_decode_v1(da, (uint32_t *)(ws + L.words), L.capWords, da.resid, (uint32_t *)(ws + L.prog), ctx->stream,
+                             (uint32_t *)(ws + L.mismatch), side ? ctx->mcStream : nullptr, ctx->mcFork, ctx->mcJoin);
         if (e == hipSuccess) {
             DecodeArgs dg = da;
             dg.gate = (const uint32_t *)(ws + L.mismatch);

@@ -115,6 +115,7 @@ struct DecV1Args {
     uint32_t round;
     uint32_t outChannels;    // interleaved channels of the output frame (= element channels for mono / stereo)
     uint32_t outFirst;       // output channel of the element's first channel
+    uint32_t *mismatch;      // null, or: k_dec_header counts the packets it gives status -4 (another element sequence) here
 };
 
 // lane states of the entropy kernel
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         rec->status = status;
         rec->pad = (uint32_t)hpos;  // first payload bit (entropy coded or raw), from the packet start
         A.statusOut[p] = status;
+        if (V.mismatch && status == -4) atomicAdd(V.mismatch, 1u);  // gates the lane decoder behind this pipeline
         if (V.round == 0 || haveElement || status != 0) A.numSamplesOut[p] = status == 0 ? R.numSamples : 0;
         // where the next element starts: known here for an uncompressed element, left by the entropy lane otherwise
         if (V.elemBit && status == 0 && haveElement && R.escape)
@@ -544,7 +546,7 @@ template <bool PUB, bool WIDE = false>
 __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block)
 {
     const DecodeArgs &A = V.d;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint32_t p = block * 64u + lane;
     const bool live = p < A.numPackets;
     const uint64_t off = live ? A.offsets[p] : 0;
@@ -675,7 +677,7 @@ template <bool FOLLOW>
 __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t block)
 {
     const DecodeArgs &A = V.d;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t q = (uint64_t)block * 32u + lane / 2;
     const bool inRange = q < (uint64_t)A.numPackets * A.numChannels;
     uint32_t p, ch;
@@ -945,15 +947,31 @@ __global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
     }
 }
 
-// ---- fused launch: entropy waves first (they are resident before any follower can wait), predictor waves behind
-// them; last, one block per packet for the uncompressed elements (nobody waits for those: their dispatch hides under
-// the entropy chain instead of costing a launch of its own)
-__global__ __launch_bounds__(64) void k_dec_fused(DecV1Args V, uint32_t nEnt, uint32_t nUnpc)
+// ---- fused launch: a launch of WORKERS (waves), four to a workgroup with consecutive worker ids, so that the waves of a
+// workgroup get a SIMD each by construction (as single-wave workgroups their SIMD was up to whatever state the launches
+// before had left in the CU's wave allocator: see alac_encode_v1_impl.hpp, worker_id).  The entropy waves are the launch's
+// serial chain (8192 symbols per lane): roles are dealt E U .. U with R = unpcPerEnt predictor waves behind every entropy
+// wave (4 for stereo: 64 packets = 128 chains = 4 x 32), so a workgroup holds at most ONE entropy wave and, while the
+// launch has no more workgroups than the chip has CUs, a CU as well.  Nothing depends on the placement: followers wait on
+// progress words in HBM, bounded.  Behind those roles, one wave per packet for the uncompressed elements (nobody waits for
+// them; their dispatch hides under the entropy chain instead of costing a launch of its own).
+constexpr int kDecWavesPerWg = 4;
+__global__ __launch_bounds__(64 * kDecWavesPerWg, 1) void k_dec_fused(DecV1Args V, uint32_t nEnt, uint32_t nUnpc, uint32_t unpcPerEnt)
 {
-    __shared__ uint32_t ring[64 * kWinStride];
-    if (blockIdx.x < nEnt) entropy_body<true>(V, ring, blockIdx.x);
-    else if (blockIdx.x < nEnt + nUnpc) unpc_fast_body<true>(V, blockIdx.x - nEnt);
-    else raw_body(V, blockIdx.x - nEnt - nUnpc, threadIdx.x, 64);
+    __shared__ uint32_t ringAll[kDecWavesPerWg][64 * kWinStride];
+    const uint32_t slot = threadIdx.x >> 6, wid = blockIdx.x * (uint32_t)kDecWavesPerWg + slot;
+    const uint32_t period = unpcPerEnt + 1, paired = nEnt * period;
+    if (wid < paired) {
+        const uint32_t t = wid / period, r = wid % period;
+        if (r == 0) {
+            entropy_body<true>(V, ringAll[slot], t);
+        } else {
+            const uint32_t b = t * unpcPerEnt + (r - 1);
+            if (b < nUnpc) unpc_fast_body<true>(V, b);
+        }
+    } else if (wid - paired < V.d.numPackets) {
+        raw_body(V, wid - paired, threadIdx.x & 63, 64);
+    }
 }
 
 __global__ __launch_bounds__(64) void k_dec_unpc(DecV1Args V)
@@ -1089,12 +1107,35 @@ static void launch_unmix_v1(const DecV1Args &V, hipStream_t st)
 }
 
 // everything after the staging of the stream: one pass of the pipeline over the elements V describes
-static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
+// side: optional second stream + fork / join events — the clears of the residual plane (328 MB at 10 000 stereo packets: 50 us)
+// and of the progress words run there beside k_dec_stage / k_dec_header and are joined in front of the entropy launch
+struct DecSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSide *side = nullptr, bool stageFirst = false)
 {
     const DecodeArgs &da = V.d;
     const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
-    (void)hipMemsetAsync(V.plane, 0, planeBytes, st);  // zero runs only move the index (k_dec_entropy)
+    const int forced0 = V.d.optFused;
+    const bool fused0 = forced0 >= 0 ? forced0 != 0 : (uint64_t)da.numPackets * da.numChannels <= 65536;
+    const bool useSide = side && side->stream && fused0;
+    hipStream_t sc = useSide ? side->stream : st;  // the clears
+    if (useSide) {
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(sc, side->fork, 0);
+    }
+    (void)hipMemsetAsync(V.plane, 0, planeBytes, sc);  // zero runs only move the index (k_dec_entropy)
+    if (useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, sc);
+    if (V.mismatch) (void)hipMemsetAsync(V.mismatch, 0, 4, st);
+    if (stageFirst)
+        hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
+                           V.capWords);
     hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
+    if (useSide) {
+        (void)hipEventRecord(side->join, sc);
+        (void)hipStreamWaitEvent(st, side->join, 0);
+    }
     const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
     const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
     // One launch (entropy lanes followed by the predictor waves, producer/consumer through HBM) where the chains are few
@@ -1104,8 +1145,13 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st)
     const int forced = V.d.optFused;
     const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= 65536;
     if (fused) {
-        (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
-        hipLaunchKernelGGL(k_dec_fused, dim3(nEnt + nUnpc + da.numPackets), dim3(64), 0, st, V, nEnt, nUnpc);
+        if (!useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
+        // predictor waves per entropy wave: 64 packets x channels / 32 chains, and enough of them for all of nUnpc
+        uint32_t per = 2 * da.numChannels;
+        while ((uint64_t)nEnt * per < nUnpc) per++;
+        const uint64_t workers = (uint64_t)nEnt * (per + 1) + da.numPackets;
+        hipLaunchKernelGGL(k_dec_fused, dim3((uint32_t)((workers + kDecWavesPerWg - 1) / kDecWavesPerWg)), dim3(64 * kDecWavesPerWg), 0, st, V,
+                           nEnt, nUnpc, per);
     } else {
         // a prime number of workgroups: escape packets that recur with a period (every 8th packet of the benchmark's signal
         // classes) must not all land on the same few workgroups
@@ -1149,6 +1195,7 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
     V.prog = prog;
     V.pubMask = da.optPubMask;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
     V.elemBit = nullptr;
+    V.mismatch = nullptr;
     V.round = 0;
     V.outChannels = da.numChannels;
     V.outFirst = 0;
@@ -1156,12 +1203,16 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
 }
 
 hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
-                            hipStream_t st)
+                            hipStream_t st, uint32_t *mismatch, hipStream_t sideStream, hipEvent_t fork, hipEvent_t join)
 {
     if (da.numPackets == 0) return hipSuccess;
-    const DecV1Args V = decode_v1_args(da, words, capWords, plane, prog);
-    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
-    return decode_v1_pass(V, st);
+    DecV1Args V = decode_v1_args(da, words, capWords, plane, prog);
+    V.mismatch = mismatch;
+    DecSide side;
+    side.stream = sideStream;
+    side.fork = fork;
+    side.join = join;
+    return decode_v1_pass(V, st, sideStream ? &side : nullptr, true);
 }
 
 // counts the packets whose status is `code` (the element-sequence mismatch of launch_decode_v1_elements)

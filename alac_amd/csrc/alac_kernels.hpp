@@ -193,8 +193,12 @@ hipError_t launch_decode(const DecodeArgs &da, hipStream_t st);
 // second generation (alac_decode_v1.hip): `words` = capWords uint32 of scratch for the re-staged stream, `plane` =
 // numPackets * numChannels * frameSize int32, `prog` = 2 * numPackets + 2 uint32 (progress words of the fused launch;
 // chain list and its two counters where the stages are separate launches)
+// mismatch (nullable): device counter of the packets whose elements are not the expected sequence (status -4), cleared and
+// counted by the pipeline itself; sideStream / fork / join (nullable): the plane and progress-word clears run there beside the
+// staging and header kernels
 hipError_t launch_decode_v1(const DecodeArgs &da, uint32_t *words, uint64_t capWords, int32_t *plane, uint32_t *prog,
-                            hipStream_t st);
+                            hipStream_t st, uint32_t *mismatch = nullptr, hipStream_t sideStream = nullptr, hipEvent_t fork = nullptr,
+                            hipEvent_t join = nullptr);
 
 // ---- > 2 channels (alac_multichannel.hip): a packet is a sequence of mono / stereo elements ----
 struct McElement {
