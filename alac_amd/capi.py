@@ -52,6 +52,8 @@ SIGNATURES = {
     "alac_hip_encode_max_output_bytes": (_u64, [C.POINTER(Format), _u32]),
     "alac_hip_encode": (_i32, [_vp, C.POINTER(Format), _vp, _vp, _u32, _vp, _u32, _vp, _i32, _vp, _u64,
                                _vp, _u64, _vp, _vp]),
+    "alac_hip_encode_segmented": (_i32, [_vp, C.POINTER(Format), _vp, _vp, _u32, _vp, _u32, _u32, _vp, _i32, _vp, _u64,
+                                         _vp, _u64, _vp, _vp]),
     "alac_hip_profile_begin": (_i32, [_vp, _u32]),
     "alac_hip_profile_end": (_i32, [_vp, C.POINTER(_u32), C.POINTER(C.c_float), C.POINTER(_u32)]),
     "alac_hip_num_stages": (_u32, []),
@@ -275,9 +277,10 @@ class Context:
                     offsets=t.empty(num_packets + 1, dtype=t.int64, device=self.device))
 
     def encode(self, fmt, pcm, num_packets, num_samples=None, seg_first=None, state=None, state_in=False,
-               bufs=None):
+               bufs=None, max_segment_packets=0):
         """pcm: uint8 cuda tensor (num_packets * fmt.packet_bytes).  Returns the buffers dict
-        (out, sizes, offsets); offsets[-1] is the total byte count.  Asynchronous."""
+        (out, sizes, offsets); offsets[-1] is the total byte count.  Asynchronous — with a segment table only if
+        max_segment_packets (the caller's bound on the longest segment, alac_hip_encode_segmented) is given."""
         with self._call() as cur:
             t = self.torch
             assert pcm.is_cuda and pcm.dtype == t.uint8 and pcm.numel() >= num_packets * fmt.packet_bytes
@@ -285,10 +288,10 @@ class Context:
             bufs = bufs or self.encode_buffers(fmt, num_packets)
             wsb = int(self.lib.alac_hip_encode_workspace_bytes(C.byref(fmt), num_packets, nseg))
             ws = self._workspace(wsb)
-            rc = self.lib.alac_hip_encode(
+            rc = self.lib.alac_hip_encode_segmented(
                 self.h, C.byref(fmt), pcm.data_ptr(),
                 None if num_samples is None else num_samples.data_ptr(), num_packets,
-                None if seg_first is None else seg_first.data_ptr(), nseg,
+                None if seg_first is None else seg_first.data_ptr(), nseg, int(max_segment_packets),
                 None if state is None else state.data_ptr(), 1 if state_in else 0,
                 ws.data_ptr(), ws.numel(), bufs["out"].data_ptr(), bufs["out"].numel(),
                 bufs["sizes"].data_ptr(), bufs["offsets"].data_ptr())

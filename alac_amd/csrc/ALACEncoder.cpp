@@ -108,7 +108,7 @@ int32_t ALACEncoder::EncodeBatch(const void *pcm, uint64_t totalSamples, uint32_
                                  uint64_t outCapacity, uint32_t *packetBytes, uint64_t *outTotalBytes)
 {
     if (!mCtx) return kALAC_ParamError;
-    if (mFastMode) return kALAC_UnimplementedError;  // broken in the reference too
+    (void)alac_hip_set_option(mCtx, "fast_mode", mFastMode ? 1 : 0);  // SetFastMode: EncodeStereoFast, codec/ALACEncoder.cu:998-1001
     alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
     const uint64_t np = (totalSamples + mFrameSize - 1) / mFrameSize;
     const uint64_t nseg = segmentPackets ? (np + segmentPackets - 1) / segmentPackets : 1;
@@ -134,7 +134,7 @@ int32_t ALACEncoder::EncodeSegments(const void *pcm, const uint32_t *numSamples,
                                     uint32_t *packetBytes, uint64_t *outTotalBytes)
 {
     if (!mCtx) return kALAC_ParamError;
-    if (mFastMode) return kALAC_UnimplementedError;
+    (void)alac_hip_set_option(mCtx, "fast_mode", mFastMode ? 1 : 0);
     alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
     uint64_t total = 0;
     mLastStatus = alac_hip_encode_host_segments(mCtx, &fmt, pcm, numSamples, numPackets, segFirst, numSegments, nullptr, 0,
@@ -164,6 +164,7 @@ void ALACEncoder::InitializeSampling(void *d_ip, AudioFormatDescription theInput
     }
     const uint32_t np = (uint32_t)ns.size();
     if (np == 0) return;
+    (void)alac_hip_set_option(mCtx, "fast_mode", mFastMode ? 1 : 0);
     alac_hip_format fmt = {mFrameSize, (uint32_t)mBitDepth, mNumChannels, mOutputSampleRate};
     const uint32_t segFirst[2] = {0, np};
     const uint64_t stateBytes = alac_hip_state_int16(&fmt) * 2ull;
@@ -182,8 +183,9 @@ void ALACEncoder::InitializeSampling(void *d_ip, AudioFormatDescription theInput
         if (ok && mStateValid) ok = hipMemcpyAsync(dState, mState, stateBytes, hipMemcpyHostToDevice, st) == hipSuccess;
     }
     if (ok) {
-        mLastStatus = alac_hip_encode(mCtx, &fmt, d_ip, (const uint32_t *)dNs, np, (const uint32_t *)dSeg, 1,
-                                      (int16_t *)dState, mStateValid ? 1 : 0, dWs, wsBytes, (uint8_t *)dOut, outMax,
+        // one chained segment of np packets: the bound is known here, so the library does not read the table back
+        mLastStatus = alac_hip_encode_segmented(mCtx, &fmt, d_ip, (const uint32_t *)dNs, np, (const uint32_t *)dSeg, 1, np,
+                                                (int16_t *)dState, mStateValid ? 1 : 0, dWs, wsBytes, (uint8_t *)dOut, outMax,
                                       (uint32_t *)dSizes, (uint64_t *)dOffs);
         ok = (mLastStatus == ALAC_HIP_noErr);
     } else {

@@ -90,7 +90,7 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask},
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
         {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
-        {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"lds_pad", &AlacOptions::ldsPad},
+        {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"fast_mode", &AlacOptions::fastMode}, {"lds_pad", &AlacOptions::ldsPad},
         {"debug_waves", &AlacOptions::debugWaves}, {"count_walk", &AlacOptions::countWalk},
         {"init_state", &AlacOptions::initState},
     };
@@ -151,8 +151,17 @@ bool ensure_second_stream(alac_hip_ctx *ctx)
 // after the stream has been synchronised: did a consumer of an in-launch hand-off give up?
 int32_t check_handoff(alac_hip_ctx *ctx)
 {
-    if (!ctx->errHost || *(volatile uint32_t *)ctx->errHost == 0) return ALAC_HIP_noErr;
-    *(volatile uint32_t *)ctx->errHost = 0;
+    if (!ctx->errHost) return ALAC_HIP_noErr;
+    volatile uint32_t *w = (volatile uint32_t *)ctx->errHost;
+    if (w[1] != 0) {  // k_check_segments: the caller's segment table contradicts the bound it gave
+        w[1] = 0;
+        w[0] = 0;
+        return fail(ctx, ALAC_HIP_ParamError,
+                    "d_seg_first is not ascending inside [0, num_packets] or a segment is longer than max_segment_packets: the "
+                    "results of the calls since the last synchronize are invalid");
+    }
+    if (w[0] == 0) return ALAC_HIP_noErr;
+    w[0] = 0;
     return fail(ctx, ALAC_HIP_MemFullError,
                 "an in-launch producer/consumer hand-off timed out: the results of the calls since the last synchronize are invalid");
 }
@@ -402,7 +411,7 @@ int32_t alac_hip_create(alac_hip_ctx **out_ctx, int32_t device, void *stream)
         alac_hip_destroy(c);
         return ALAC_HIP_MemFullError;
     }
-    *c->errHost = 0;
+    c->errHost[0] = c->errHost[1] = 0;
     *out_ctx = c;
     return ALAC_HIP_noErr;
 }
@@ -509,14 +518,31 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
                                const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
                                uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
                                uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
-                               uint32_t *d_packet_bytes, uint64_t *d_packet_offsets);
+                               uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, uint32_t maxSegHint);
 
 // one mono / stereo batch; `timed` = this call may consume a slot of the armed stage timing
 static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
                            const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
                            uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
                            uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
-                           uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, bool timed);
+                           uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, bool timed, uint32_t maxSegHint);
+
+int32_t alac_hip_encode_segmented(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                                  const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
+                                  uint32_t num_segments, uint32_t max_segment_packets, int16_t *d_state, int32_t state_in,
+                                  void *d_workspace, uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
+                                  uint32_t *d_packet_bytes, uint64_t *d_packet_offsets)
+{
+    if (!ctx) return ALAC_HIP_ParamError;
+    if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
+    if (fmt->num_channels > 2)
+        return encode_elements(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, d_state, state_in,
+                               d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets,
+                               max_segment_packets);
+    return encode_core(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, d_state, state_in,
+                       d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets, true,
+                       max_segment_packets);
+}
 
 int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
                         const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
@@ -524,20 +550,15 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
                         uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
                         uint32_t *d_packet_bytes, uint64_t *d_packet_offsets)
 {
-    if (!ctx) return ALAC_HIP_ParamError;
-    if (!format_ok(fmt)) return fail(ctx, ALAC_HIP_ParamError, "unsupported format");
-    if (fmt->num_channels > 2)
-        return encode_elements(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, d_state, state_in,
-                               d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets);
-    return encode_core(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, d_state, state_in,
-                       d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets, true);
+    return alac_hip_encode_segmented(ctx, fmt, d_pcm, d_num_samples, num_packets, d_seg_first, num_segments, 0, d_state, state_in,
+                                     d_workspace, workspace_bytes, d_out, out_capacity, d_packet_bytes, d_packet_offsets);
 }
 
 static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
                                const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
                                uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
                                uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
-                               uint32_t *d_packet_bytes, uint64_t *d_packet_offsets)
+                               uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, uint32_t maxSegHint)
 {
     if (num_packets == 0) return ALAC_HIP_noErr;
     if (!d_pcm || !d_workspace || !d_out || !d_packet_bytes || !d_packet_offsets)
@@ -588,7 +609,7 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
         ctx->stream = st;
         rc = encode_core(ctx, &gf, ws + G.gather, ns, G.count * num_packets, seg, G.count * num_segments, gstate, state_in,
                          ws + G.sub, G.subBytes, ws + G.out, G.outCap, (uint32_t *)(ws + G.sizes), (uint64_t *)(ws + G.offs),
-                         false);
+                         false, maxSegHint);
         ctx->stream = mainStream;
         if (gstate && rc == ALAC_HIP_noErr)
             for (uint32_t k = 0; k < G.count && copyErr == hipSuccess; k++)
@@ -625,7 +646,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
                            const uint32_t *d_num_samples, uint32_t num_packets, const uint32_t *d_seg_first,
                            uint32_t num_segments, int16_t *d_state, int32_t state_in, void *d_workspace,
                            uint64_t workspace_bytes, uint8_t *d_out, uint64_t out_capacity,
-                           uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, bool timed)
+                           uint32_t *d_packet_bytes, uint64_t *d_packet_offsets, bool timed, uint32_t maxSegHint)
 {
     if (num_packets == 0) return ALAC_HIP_noErr;
     if (!d_pcm || !d_workspace || !d_out || !d_packet_bytes || !d_packet_offsets)
@@ -687,7 +708,12 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
         if (ev) ctx->profSub.push_back(v1_sub_batches(num_segments, ctx->vs.numSub, fmt->num_channels));
         // packets per segment: the pipeline runs once per packet position (a chained segment is serial)
         uint32_t maxSeg = 1;
-        if (d_seg_first) {
+        if (d_seg_first && maxSegHint) {
+            // the caller knows how long its longest segment is (alac_hip_encode_segmented): no read-back of the table, no
+            // host wait.  The bound is checked on the device; a table that contradicts it fails the next synchronize.
+            maxSeg = maxSegHint < num_packets ? maxSegHint : num_packets;
+            launch_check_segments(d_seg_first, num_segments, num_packets, maxSeg, ctx->errDev ? ctx->errDev + 1 : nullptr, ctx->stream);
+        } else if (d_seg_first) {
             std::vector<uint32_t> sf(num_segments + 1);
             if (hipMemcpyAsync(sf.data(), d_seg_first, (num_segments + 1) * 4ull, hipMemcpyDeviceToHost, ctx->stream) !=
                     hipSuccess ||
@@ -1053,9 +1079,11 @@ int32_t alac_hip_encode_host_segments(alac_hip_ctx *ctx, const alac_hip_format *
     if (h_state && state_in)
         if ((e = hipMemcpyAsync(dState.p, h_state, stateBytes, hipMemcpyHostToDevice, st)))
             return fail(ctx, ALAC_HIP_ParamError, "H2D state", e);
-    int32_t rc = alac_hip_encode(ctx, fmt, dPcm.p, (const uint32_t *)dNs.p, np, (const uint32_t *)dSeg.p, nseg,
-                                 (int16_t *)dState.p, (h_state && state_in) ? 1 : 0, dWs.p, wsBytes,
-                                 (uint8_t *)dOut.p, outMax, (uint32_t *)dSizes.p, (uint64_t *)dOffs.p);
+    uint32_t maxSeg = 1;
+    for (uint32_t s2 = 0; s2 < nseg; s2++) maxSeg = h_seg_first[s2 + 1] - h_seg_first[s2] > maxSeg ? h_seg_first[s2 + 1] - h_seg_first[s2] : maxSeg;
+    int32_t rc = alac_hip_encode_segmented(ctx, fmt, dPcm.p, (const uint32_t *)dNs.p, np, (const uint32_t *)dSeg.p, nseg, maxSeg,
+                                           (int16_t *)dState.p, (h_state && state_in) ? 1 : 0, dWs.p, wsBytes,
+                                           (uint8_t *)dOut.p, outMax, (uint32_t *)dSizes.p, (uint64_t *)dOffs.p);
     if (rc != ALAC_HIP_noErr) return rc;
     uint64_t total = 0;
     if ((e = hipMemcpyAsync(&total, (uint64_t *)dOffs.p + np, 8, hipMemcpyDeviceToHost, st)) ||

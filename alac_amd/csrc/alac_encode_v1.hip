@@ -14,6 +14,21 @@ __global__ void k_init_state(int16_t *state, uint32_t numSegments)
     state[i] = (int16_t)(k == 0 ? 1216 : k == 1 ? -928 : k == 2 ? -64 : 0);
 }
 
+__global__ void k_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= numSegments) return;
+    const uint32_t a = segFirst[s], b = segFirst[s + 1];
+    const bool bad = b < a || b > numPackets || b - a > maxSeg || (s == 0 && a != 0) || (s + 1 == numSegments && b != numPackets);
+    if (bad && err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err,
+                           hipStream_t st)
+{
+    hipLaunchKernelGGL(k_check_segments, dim3((numSegments + 255) / 256), dim3(256), 0, st, segFirst, numSegments, numPackets, maxSeg, err);
+}
+
 // chains beyond what one 2-lane predictor wave per SIMD holds (1024 SIMDs x 32 chains x 2): throughput regime
 bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt)
 {
@@ -99,6 +114,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     // rows that live in the workspace and hold no caller state are never read before they are written: the kernels of the first
     // packet position take init_coefs as constants (load_row) instead of a k_init_state launch writing them first
     A.virgin = (!vb.stateInitialised && vb.stateInternal) ? 1u : 0u;
+    if (vb.opt.fastMode && channels == 2) A.virgin = 0;  // no search launch takes init_coefs as constants there: write the rows
     if (!vb.stateInitialised && (!A.virgin || vb.opt.initState))
         hipLaunchKernelGGL(k_init_state, dim3((ea.numSegments * 64 + 255) / 256), dim3(256), 0, st, vb.state,
                            ea.numSegments);

@@ -1077,6 +1077,26 @@ __global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_search2_fused(V1Args A,
     }
 }
 
+// SetFastMode (stereo): what EncodeStereoFast fixes instead of searching (codec/ALACEncoder.cu:613-618) — mixRes 0, numU = numV = 8,
+// no escape estimate (the escape decision comes from the bits written, :705-729 = k_finalize's rule) — and the header
+// coefficients = row 7 as it stands before the pass (:655-671)
+static __global__ void k_decide_fast(V1Args A)
+{
+    const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p, N;
+    if (!seg_packet(A.S, seg, p, N)) return;
+    PacketRec *rec = A.recs + p;
+    for (uint32_t c = 0; c < 2; c++) {
+        rec->c[c].num = 8;
+        rec->c[c].bits = 0;
+        const int16_t *row = A.state + (uint64_t)seg * 64 + c * 32 + 16;
+        for (uint32_t k = 0; k < 8; k++) rec->c[c].coefs[k] = row[k];
+    }
+    rec->mixRes = 0;
+    rec->numSamples = N;
+    rec->escape = 0;
+}
+
 // numU / numV, escape estimate (codec/ALACEncoder.cu:438-461, mono :899-915), header coefficients
 template <int DEPTH, int CH>
 __global__ void k_decide2(V1Args A)
@@ -1830,7 +1850,7 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
         // predictor waves wait, per chain, for rows that p's final pass still owns (rowReady).  The rest of p + 1 waits for
         // p's final pass.  58-75 % of packets choose 4 taps on both channels: their successor's search (a third of a
         // position's serial chain) disappears behind the final pass.
-        const bool overlap = opt.overlapPos != 0 && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
+        const bool overlap = opt.overlapPos != 0 && !(CH == 2 && opt.fastMode) && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
                              A.S.frameSize / 8 < 65536u && opt.fused != 0;
         if (overlap) {
             A.rowReady = A0.ovRowReady;
@@ -1868,7 +1888,8 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             // escape and the packet sizes itself (k_final_fused<.., FOLD>), and ONE memset clears the progress words of all three
             // producer/consumer launches of the position.
             // (experiments: bit 0 of "fold" = the converge launch, bit 1 = the final launch, bit 2 = one memset for all flag words)
-            const bool foldOk = fuse && !narrow;
+            const bool fast = CH == 2 && opt.fastMode != 0;  // SetFastMode: no search passes at all (mono has no fast form)
+            const bool foldOk = fuse && !narrow && !fast;
             const bool latFold2 = foldOk && (opt.fold & 1), latFold = foldOk && (opt.fold & 2), oneMemset = foldOk && (opt.fold & 4);
             latFoldAny = latFoldAny || latFold;
             if (foldOk) {
@@ -1877,7 +1898,14 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 A.foldDecide = latFold ? 1 : 0;
                 if (oneMemset) (void)hipMemsetAsync(A.flags, 0, (size_t)2 * (A0.chainsPad / 8 + 16) * 4, sp);
             }
-            if constexpr (CH == 2) {
+            if (fast) {
+                if (e) {
+                    (void)hipEventRecord(e[kStageGol1], sp);
+                    (void)hipEventRecord(e[kStageLms2], sp);
+                    (void)hipEventRecord(e[kStageGol2], sp);
+                }
+                hipLaunchKernelGGL(k_decide_fast, dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
+            } else if constexpr (CH == 2) {
                 const bool wide = A.wide81 != 0;
                 const uint32_t nLms1 = wide ? cblocks : nLms;
                 // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
@@ -1916,33 +1944,35 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 (void)hipEventRecord(e[kStageGol1], sp);
             }
             if (overlap && pos > 0) (void)hipStreamWaitEvent(sp, vs.join[(pos - 1) & 1], 0);  // final pass of pos - 1
-            if (e) (void)hipEventRecord(e[kStageLms2], sp);
-            const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
-            if (latFold2) {
-                if (!oneMemset) (void)hipMemsetAsync(A.flags2, 0, ((size_t)(nb3 + nb7) * 4 + 15) & ~(size_t)15, sp);
-                hipLaunchKernelGGL((k_search2_fused<DEPTH, CH>), dim3((nb3 + nb7 + 2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nb3, nb3 + nb7, cblocks,
-                                   chanBits);
-            } else if (narrow)
-                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
-            else if (thru && opt.searchFused)  // as below, and every lane counts its own residuals
-                hipLaunchKernelGGL((k_search2_lane<DEPTH, CH>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3, chanBits);
-            else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
-                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
-            else if (fuse)  // latency regime: workers (one wave per SIMD by construction)
-                hipLaunchKernelGGL((k_lms_search2_w<DEPTH, CH>), dim3((3 * nb3 + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
-                                   nb3, nb7);
-            else
-                hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
-            if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
-            if (e) (void)hipEventRecord(e[kStageGol2], sp);
-            if (!latFold2 && (!(thru && opt.searchFused) || narrow)) {
-                if (fuse)
-                    hipLaunchKernelGGL(k_gol_count2_w<CH>, dim3((2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
-                                       cblocks, chanBits);
+            if (!fast) {
+                if (e) (void)hipEventRecord(e[kStageLms2], sp);
+                const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
+                if (latFold2) {
+                    if (!oneMemset) (void)hipMemsetAsync(A.flags2, 0, ((size_t)(nb3 + nb7) * 4 + 15) & ~(size_t)15, sp);
+                    hipLaunchKernelGGL((k_search2_fused<DEPTH, CH>), dim3((nb3 + nb7 + 2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nb3, nb3 + nb7, cblocks,
+                                       chanBits);
+                } else if (narrow)
+                    hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
+                else if (thru && opt.searchFused)  // as below, and every lane counts its own residuals
+                    hipLaunchKernelGGL((k_search2_lane<DEPTH, CH>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3, chanBits);
+                else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
+                    hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
+                else if (fuse)  // latency regime: workers (one wave per SIMD by construction)
+                    hipLaunchKernelGGL((k_lms_search2_w<DEPTH, CH>), dim3((3 * nb3 + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
+                                       nb3, nb7);
                 else
-                    hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+                    hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
+                if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+                if (e) (void)hipEventRecord(e[kStageGol2], sp);
+                if (!latFold2 && (!(thru && opt.searchFused) || narrow)) {
+                    if (fuse)
+                        hipLaunchKernelGGL(k_gol_count2_w<CH>, dim3((2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
+                                           cblocks, chanBits);
+                    else
+                        hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+                }
+                if (!latFold) hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             }
-            if (!latFold) hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             if (overlap) (void)hipEventRecord(vs.stagger[pos & 1], sp);
             if (e) (void)hipEventRecord(e[kStageLms3], sp);
             if (thru) {

@@ -107,6 +107,7 @@ struct AlacOptions {
     int32_t debugWaves = 0;    // "debug_waves"  wave placement / timing stamps of the fused final launch into the workspace (tools/wave_map.py)
     int32_t ldsPad = 0;        // "lds_pad"      ALAC_HIP_LDS_PAD     dynamic LDS bytes added to the single-wave workgroups of the fused final
                                //                                     launch (caps the workgroups a CU takes: experiments)
+    int32_t fastMode = 0;      // "fast_mode"    (no env)             ALACEncoder::SetFastMode: stereo elements without the search (EncodeStereoFast)
     int32_t fold = 6;          // "fold"         ALAC_HIP_FOLD        latency regime: converge passes || counts in one launch, decision and
                                //                                     packet sizes inside the final launch, no k_init_state / k_decide* / k_finalize
     int32_t searchFused = 1;   // "search_fused" ALAC_HIP_SEARCH_FUSED throughput regime: search passes + their bit counts in one lane
@@ -143,6 +144,9 @@ struct V1Streams {
     hipStream_t side[kMaxSubBatches - 1];
     hipEvent_t fork, stagger[kMaxSubBatches - 1], join[kMaxSubBatches - 1];
 };
+// *err = 1 (system scope) unless segFirst[0 .. numSegments] ascends inside [0, numPackets] with no step above maxSeg
+void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err,
+                           hipStream_t st);
 // sub-batches actually used for a batch of numSegments segments
 uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels);
 bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt);

@@ -125,6 +125,19 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
                         uint8_t *d_out, uint64_t out_capacity, uint32_t *d_packet_bytes,
                         uint64_t *d_packet_offsets);
 
+/* The same with the caller's bound on the packets of a segment.  The pipeline runs once per packet position of the longest
+ * segment, so the host has to know that length: alac_hip_encode reads d_seg_first back (one blocking copy per call) when it is
+ * given a table; here max_segment_packets (> 0) is taken on trust, nothing is read back and the call stays asynchronous.  The
+ * table is checked on the device (ascending, 0 .. num_packets, no segment above the bound); if it fails, the results are
+ * invalid and the next alac_hip_synchronize returns kALAC_ParamError.  An over-estimate only costs idle launches.
+ * max_segment_packets = 0: exactly alac_hip_encode.  (The fork's InitializeSampling has no counterpart: one file, one chain.) */
+int32_t alac_hip_encode_segmented(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
+                                  const uint32_t *d_num_samples, uint32_t num_packets,
+                                  const uint32_t *d_seg_first, uint32_t num_segments,
+                                  uint32_t max_segment_packets, int16_t *d_state, int32_t state_in,
+                                  void *d_workspace, uint64_t workspace_bytes, uint8_t *d_out,
+                                  uint64_t out_capacity, uint32_t *d_packet_bytes, uint64_t *d_packet_offsets);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around the three kernels of
  * alac_hip_encode (the instrumented counterpart of the dead cudaEvent timing in
  * codec/CudaAlacEncoder.cu:52-65).  begin() arms up to max_calls encode calls; end() synchronises and

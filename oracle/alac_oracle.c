@@ -535,6 +535,7 @@ struct oalac_encoder {
     uint32_t totalBytes, maxFrameBytes;
     uint32_t info[6];
     oalac_hooks hooks;
+    int fastMode; /* SetFastMode, ALACEncoder.h:44 */
 };
 
 static const oalac_hooks k_own_hooks = {oalac_pc_block, oalac_unpc_block, oalac_dyn_comp, oalac_dyn_decomp};
@@ -589,6 +590,9 @@ void oalac_encoder_free(oalac_encoder *e)
 }
 
 void oalac_encoder_set_hooks(oalac_encoder *e, const oalac_hooks *h) { e->hooks = h ? *h : k_own_hooks; }
+
+/* SetFastMode, ALACEncoder.h:44: stereo elements go through EncodeStereoFast (ALACEncoder.cu:998-1001) */
+void oalac_encoder_set_fast_mode(oalac_encoder *e, int fast) { e->fastMode = fast ? 1 : 0; }
 
 /* :1524-1531 */
 void oalac_encoder_reset_state(oalac_encoder *e)
@@ -798,6 +802,68 @@ static int32_t encode_stereo(oalac_encoder *e, uint8_t *out, uint64_t *pos, cons
     return OALAC_noErr;
 }
 
+/* EncodeStereoFast, ALACEncoder.cu:564-745: no search — mixRes = kDefaultMixRes (0), numU = numV = kDefaultNumUV (8),
+ * one pc_block pass over the whole packet on row 7 (whose coefficients, as they stand BEFORE the pass, go into the
+ * header), escape decided from the bits actually written.  (In the fork the call site hands it the HOST buffer while its
+ * mixNN are device kernels, :1001 — the path cannot run there; what is restated is Apple's function as written.) */
+static int32_t encode_stereo_fast(oalac_encoder *e, uint8_t *out, uint64_t *pos, const uint8_t *pcm,
+                                  uint32_t stride, uint32_t ch, uint32_t numSamples)
+{
+    uint64_t startPos = *pos;
+    uint32_t bytesShifted = bytes_shifted_for(e->bitDepth); /* :596-603 */
+    uint32_t chanBits = e->bitDepth - bytesShifted * 8 + 1;
+    uint32_t partial = (numSamples == e->frameSize) ? 0 : 1;
+    const int32_t mixBits = 2, mixRes = 0;                  /* :613-614 */
+    const uint32_t numU = 8, numV = 8, pbFactor = 4, mode = 0; /* :615-618 */
+    const uint32_t pb = (pbFactor * OALAC_PB0) / 4;
+    uint32_t bits1 = 0, bits2 = 0;
+    int32_t status;
+
+    /* :623-644 */
+    mix_strided(pcm, stride, e->bitDepth, e->mixU, e->mixV, (int32_t)numSamples, mixBits, mixRes, e->shiftUV,
+                (int32_t)bytesShifted);
+    /* :649-671 header + coefficients */
+    oalac_put_bits(out, pos, 0, 12);
+    oalac_put_bits(out, pos, (partial << 3) | (bytesShifted << 1), 4);
+    if (partial) oalac_put_bits(out, pos, numSamples, 32);
+    oalac_put_bits(out, pos, (uint32_t)mixBits, 8);
+    oalac_put_bits(out, pos, (uint32_t)mixRes, 8);
+    oalac_put_bits(out, pos, (mode << 4) | OALAC_DENSHIFT, 8);
+    oalac_put_bits(out, pos, (pbFactor << 5) | numU, 8);
+    for (uint32_t i = 0; i < numU; i++) oalac_put_bits(out, pos, (uint32_t)(int32_t)e->coefsU[ch][numU - 1][i], 16);
+    oalac_put_bits(out, pos, (mode << 4) | OALAC_DENSHIFT, 8);
+    oalac_put_bits(out, pos, (pbFactor << 5) | numV, 8);
+    for (uint32_t i = 0; i < numV; i++) oalac_put_bits(out, pos, (uint32_t)(int32_t)e->coefsV[ch][numV - 1][i], 16);
+    /* :674-686 */
+    if (bytesShifted != 0) {
+        uint32_t bitShift = bytesShifted * 8;
+        for (uint32_t i = 0; i < numSamples * 2; i += 2) {
+            uint32_t val = ((uint32_t)e->shiftUV[i] << bitShift) | (uint32_t)e->shiftUV[i + 1];
+            oalac_put_bits(out, pos, val, bitShift * 2);
+        }
+    }
+    /* :690-702 */
+    e->hooks.pc_block(e->mixU, e->predU, (int32_t)numSamples, e->coefsU[ch][numU - 1], (int32_t)numU, chanBits, OALAC_DENSHIFT);
+    status = e->hooks.dyn_comp(OALAC_MB0, pb, OALAC_KB0, e->predU, out, pos, (int32_t)numSamples, (int32_t)chanBits, &bits1);
+    if (status) return status;
+    e->hooks.pc_block(e->mixV, e->predV, (int32_t)numSamples, e->coefsV[ch][numV - 1], (int32_t)numV, chanBits, OALAC_DENSHIFT);
+    status = e->hooks.dyn_comp(OALAC_MB0, pb, OALAC_KB0, e->predV, out, pos, (int32_t)numSamples, (int32_t)chanBits, &bits2);
+    if (status) return status;
+    /* :705-716 */
+    uint32_t minBits = (bits1 + numU * 16) + (bits2 + numV * 16) + 8 * 8 + (partial ? 32 : 0);
+    if (bytesShifted != 0) minBits += numSamples * (bytesShifted * 8) * 2;
+    uint32_t escapeBits = numSamples * e->bitDepth * 2 + (partial ? 32 : 0) + 2 * 8;
+    int doEscape = (minBits >= escapeBits);
+    /* :718-729 */
+    if (!doEscape && (uint32_t)(*pos - startPos) >= escapeBits) doEscape = 1;
+    e->info[0] = (uint32_t)doEscape; e->info[1] = 0; e->info[2] = numU; e->info[3] = numV; e->info[4] = bits1; e->info[5] = bits2;
+    if (doEscape) { /* :731-742 */
+        *pos = startPos;
+        encode_stereo_escape(e, out, pos, pcm, stride, numSamples);
+    }
+    return OALAC_noErr;
+}
+
 /* mono input widening: gpu_copyNNToPredictor, ALACEncoder.cu:1312-1382 (the fork's indexing of
  * those kernels is broken; the intended per-sample math is what is restated) */
 static void copy_to_predictor(const uint8_t *pcm, uint32_t stride, uint32_t bitDepth, int32_t *out, uint16_t *shiftBuf,
@@ -924,7 +990,8 @@ int32_t oalac_encode_packet(oalac_encoder *e, const uint8_t *pcm, uint32_t numSa
     if (e->numChannels == 2) {
         oalac_put_bits(out, &pos, 1 /* ID_CPE */, 3);
         oalac_put_bits(out, &pos, 0, 4);
-        status = encode_stereo(e, out, &pos, pcm, 2, 0, numSamples);
+        status = e->fastMode ? encode_stereo_fast(e, out, &pos, pcm, 2, 0, numSamples)
+                             : encode_stereo(e, out, &pos, pcm, 2, 0, numSamples); /* :998-1001 */
     } else if (e->numChannels == 1) {
         oalac_put_bits(out, &pos, 0 /* ID_SCE */, 3);
         oalac_put_bits(out, &pos, 0, 4);
@@ -944,7 +1011,8 @@ int32_t oalac_encode_packet(oalac_encoder *e, const uint8_t *pcm, uint32_t numSa
             oalac_put_bits(out, &pos, tag, 3);
             if (tag == 1) {
                 oalac_put_bits(out, &pos, stereoTag++, 4);
-                status = encode_stereo(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples);
+                status = e->fastMode ? encode_stereo_fast(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples)
+                                     : encode_stereo(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples);
                 ci += 2;
             } else {
                 oalac_put_bits(out, &pos, monoTag++, 4);

@@ -85,6 +85,7 @@ typedef struct oalac_encoder oalac_encoder;
 oalac_encoder *oalac_encoder_new(uint32_t frameSize, uint32_t bitDepth, uint32_t numChannels,
                                  uint32_t sampleRate);
 void oalac_encoder_free(oalac_encoder *e);
+void oalac_encoder_set_fast_mode(oalac_encoder *e, int fast);
 void oalac_encoder_set_hooks(oalac_encoder *e, const oalac_hooks *h);
 /* reset the persistent coefficient rows to init_coefs (start of an independent segment) */
 void oalac_encoder_reset_state(oalac_encoder *e);

@@ -69,6 +69,7 @@ class Oracle:
         lib.oalac_encoder_new.restype = C.c_void_p
         lib.oalac_encoder_free.argtypes = [C.c_void_p]
         lib.oalac_encoder_set_hooks.argtypes = [C.c_void_p, C.POINTER(Hooks)]
+        lib.oalac_encoder_set_fast_mode.argtypes = [C.c_void_p, C.c_int]
         lib.oalac_encoder_reset_state.argtypes = [C.c_void_p]
         lib.oalac_encoder_get_state.argtypes = [C.c_void_p, i16p]
         lib.oalac_encoder_set_state.argtypes = [C.c_void_p, i16p]
@@ -159,8 +160,12 @@ class Oracle:
         return int(self.lib.oalac_fnv1a64(_ptr(data, u8p), data.size, seed))
 
     # ---- drivers -----------------------------------------------------------------------
-    def encoder(self, frame_size=4096, depth=16, channels=2, rate=44100, hooks=None):
-        return OracleEncoder(self, frame_size, depth, channels, rate, hooks)
+    def encoder(self, frame_size=4096, depth=16, channels=2, rate=44100, hooks=None, fast=False):
+        """fast: SetFastMode(true) — stereo elements through EncodeStereoFast (no search)"""
+        enc = OracleEncoder(self, frame_size, depth, channels, rate, hooks)
+        if fast:
+            self.lib.oalac_encoder_set_fast_mode(enc.h, 1)
+        return enc
 
     def decoder(self, cookie, hooks=None):
         return OracleDecoder(self, cookie, hooks)

@@ -45,3 +45,33 @@ def test_ragged_segment_count(gpu_ctx, oracle, depth, channels):
     nseg = 1100 if channels == 2 else 2100
     _check(gpu_ctx, oracle, alac_amd.make_format(1024, depth, channels), nseg, 3,
            [0, 1, 2, 7, 8, 15, 16, 17, 31, 32, 63, 64, nseg // 2, nseg - 18, nseg - 17, nseg - 16, nseg - 2, nseg - 1])
+
+
+def test_segment_bound_instead_of_read_back(gpu_ctx, oracle):
+    """alac_hip_encode_segmented: with the caller's bound on the segment length nothing is read back; an over-estimate gives the
+    same bytes, a table that contradicts the bound fails the next synchronize (kALAC_ParamError) instead of encoding garbage"""
+    import torch
+    from alac_amd.capi import AlacError
+    fmt = alac_amd.make_format(1024, 16, 2)
+    seg_first = [0, 3, 4, 9, 12]
+    n = seg_first[-1]
+    pcm = alac_amd.synth_pcm(11, n, fmt)
+    d = torch.from_numpy(pcm).cuda()
+    sf = torch.tensor(seg_first, dtype=torch.int32).cuda()
+    ref, ref_sizes = gpu_ctx.encode_to_host(fmt, d, n, seg_first=sf)
+    for bound in (5, 8, 1000):
+        s, z = gpu_ctx.encode_to_host(fmt, d, n, seg_first=sf, max_segment_packets=bound)
+        assert np.array_equal(z, ref_sizes) and np.array_equal(s, ref), bound
+    enc = oracle.encoder(1024, 16, 2)
+    off = 0
+    for a, b in zip(seg_first[:-1], seg_first[1:]):
+        enc.reset()
+        want, _ = enc.encode_stream(pcm[a * fmt.packet_bytes:b * fmt.packet_bytes], (b - a) * 1024, 0)
+        assert np.array_equal(ref[off:off + len(want)], want)
+        off += len(want)
+    gpu_ctx.encode(fmt, d, n, seg_first=sf, max_segment_packets=4)  # the third segment has 5 packets
+    with pytest.raises(AlacError) as ei:
+        gpu_ctx.synchronize()
+    assert ei.value.code == -50 and "max_segment_packets" in str(ei.value)
+    s, z = gpu_ctx.encode_to_host(fmt, d, n, seg_first=sf, max_segment_packets=5)  # the error is consumed
+    assert np.array_equal(s, ref)

@@ -1,0 +1,62 @@
+"""SetFastMode(true) (codec/ALACEncoder.h:44): stereo elements coded by EncodeStereoFast (codec/ALACEncoder.cu:564-745) — no
+mixRes / numUV search, mixRes 0, eight taps on row 7, escape decided from the bits written.  The fork cannot run this path (its
+call site hands the host buffer to device kernels, :1001), so the anchor is the oracle's restatement of Apple's function; the
+packets must also decode back to the input through the ordinary decoder, and be a valid (if larger) ALAC stream."""
+import numpy as np
+import pytest
+
+import alac_amd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("depth,channels", [(16, 2), (24, 2), (20, 2), (32, 2), (16, 1), (16, 6)])
+def test_fast_mode_matches_oracle_and_round_trips(gpu_ctx, oracle, depth, channels):
+    import torch
+    fmt = alac_amd.make_format(4096, depth, channels)
+    n = 40
+    pcm = alac_amd.synth_pcm(0, n, fmt) if channels <= 2 else np.frombuffer(
+        __import__("container_lib").music_like(n * 4096, channels, depth, seed=3), np.uint8).copy()
+    d = torch.from_numpy(pcm).cuda()
+    seg_first = torch.tensor([0, 1, 2, 10, 11, 30, n], dtype=torch.int32).cuda()  # chained segments: row 7 carries over
+    with gpu_ctx.options(fast_mode=1):
+        s, z = gpu_ctx.encode_to_host(fmt, d, n, seg_first=seg_first)
+        s1, z1 = gpu_ctx.encode_to_host(fmt, d, n)  # independent packets
+    ref_enc = oracle.encoder(4096, depth, channels, fast=True)
+    off = 0
+    sf = seg_first.cpu().numpy()
+    for a, b in zip(sf[:-1], sf[1:]):
+        ref_enc.reset()
+        want, wz = ref_enc.encode_stream(pcm[a * fmt.packet_bytes:b * fmt.packet_bytes], (b - a) * 4096, 0)
+        assert np.array_equal(z[a:b], wz), (a, b)
+        assert np.array_equal(s[off:off + len(want)], want), (a, b)
+        off += len(want)
+    want1, wz1 = oracle.encoder(4096, depth, channels, fast=True).encode_stream(pcm, n * 4096, 1)
+    assert np.array_equal(z1, wz1) and np.array_equal(s1, want1)
+    # and the search-free stream differs from the searched one somewhere (the option really switches the path) ...
+    s0, z0 = gpu_ctx.encode_to_host(fmt, d, n)
+    if channels != 1:
+        assert not (np.array_equal(z0, z1) and np.array_equal(s0, s1))
+    else:
+        assert np.array_equal(s0, s1)  # mono has no fast form (codec/ALACEncoder.cu:1011-1019)
+    # ... and decodes back to the input
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum(z1.astype(np.int64))])).cuda()
+    out, ns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), torch.from_numpy(s1).cuda(), offs, n)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and np.array_equal(out.cpu().numpy(), pcm)
+
+
+def test_fast_mode_large_batches(gpu_ctx, oracle):
+    """the latency (> 4096 chains) and throughput (> 65 536 chains) regimes in fast mode, sampled against the oracle"""
+    import torch
+    for frame, n in ((4096, 3000), (256, 40000)):
+        fmt = alac_amd.make_format(frame, 16, 2)
+        pcm = alac_amd.synth_pcm(0, n, fmt)
+        with gpu_ctx.options(fast_mode=1):
+            s, z = gpu_ctx.encode_to_host(fmt, torch.from_numpy(pcm).cuda(), n)
+        offs = np.concatenate([[0], np.cumsum(z.astype(np.int64))])
+        enc = oracle.encoder(frame, 16, 2, fast=True)
+        for p in list(range(0, n, 211)) + [n - 1]:
+            enc.reset()
+            pk = enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], frame)
+            assert z[p] == len(pk) and np.array_equal(s[offs[p]:offs[p + 1]], pk), (frame, p)

@@ -313,3 +313,32 @@ def test_multichannel_over_reference_stages(oracle, ref):
         st, out, n = dec.decode_packet(a[off:off + int(z)], fmt.bytes_per_frame)
         assert st == 0 and np.array_equal(out, pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes])
         off += int(z)
+
+
+def test_fast_mode_restatement_round_trips_and_is_larger(oracle):
+    """EncodeStereoFast restated (oracle/alac_oracle.c, codec/ALACEncoder.cu:564-745): valid ALAC (decodes back through the
+    decoder restatement), mixRes 0 / 8 + 8 taps in every compressed packet header, never smaller in total than the searched
+    encode, and mono streams are unaffected."""
+    import alac_amd
+    fmt = alac_amd.make_format(4096, 16, 2)
+    n = 24
+    pcm = alac_amd.synth_pcm(0, n, fmt)
+    fast = oracle.encoder(4096, 16, 2, fast=True)
+    slow = oracle.encoder(4096, 16, 2)
+    sf, zf = fast.encode_stream(pcm, n * 4096, 0)
+    ss, zs = slow.encode_stream(pcm, n * 4096, 0)
+    assert len(sf) >= len(ss)
+    dec = oracle.decoder(fast.cookie())
+    off = 0
+    for p in range(n):
+        pk = sf[off:off + int(zf[p])]
+        st, out, ns = dec.decode_packet(pk, fmt.bytes_per_frame)
+        assert st == 0 and ns == 4096 and np.array_equal(out, pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes]), p
+        if int(zf[p]) < 16000:
+            # a compressed packet: 3 + 4 tag bits, 12 zero bits, 4 flag bits, then mixBits, mixRes, mode / denShift, pbFactor / numU
+            bits = int.from_bytes(bytes(pk[:8]), "big") >> (64 - 55)
+            assert (bits >> 24) & 0xff == 2 and (bits >> 16) & 0xff == 0 and bits & 0xff == (4 << 5) | 8, p
+        off += int(zf[p])
+    m1 = oracle.encoder(4096, 16, 1, fast=True).encode_stream(pcm[:8 * 8192], 8 * 4096, 0)
+    m0 = oracle.encoder(4096, 16, 1).encode_stream(pcm[:8 * 8192], 8 * 4096, 0)
+    assert np.array_equal(m1[0], m0[0])
