@@ -192,25 +192,23 @@ def baseline_metric():
 
 def kernel_symbol(stage, fused, depth, thru=False):
     """HIP kernel behind a bench stage name (what rocprofv3's kernel stats list)."""
-    if stage == "lms_final" and any(f.startswith("lms_final") for f in fused):
-        if thru:
-            return (f"k_class_final<{depth}, 2, 8> || k_class_final<{depth}, 2, 4> (final pc_block pass + final dyn_comp of a chain in "
-                    "ONE lane, per packet class, side by side; + k_class_count / k_class_assign)")
-        return f"k_final_fused<{depth}, 2, 4, 2> (final pc_block pass || final dyn_comp, one launch)"
-    if stage == "lms_search1" and any(f.startswith("lms_search1") for f in fused):
-        return f"k_search1_fused<{depth}, 4, 2> (mixRes search passes || their dyn_comp counts, one launch)"
-    if stage == "lms_search2" and any(f.startswith("lms_search2") for f in fused):
-        return f"k_search2_fused<{depth}, 2> (converge passes || their dyn_comp counts, one launch)"
-    if thru:  # throughput regime: separate launches, final pass per packet class on two streams
-        return {"lms_search1": f"k_lms_search1<{depth}, 8, 1>", "golomb_count1": "k_gol_count1<2>",
-                "lms_search2": f"k_lms_search2<{depth}, 2, 4, 1, 8, 1, 2>", "golomb_count2": "k_gol_count2<2>",
-                "lms_final": f"k_class_pred<{depth}, 2, 8, 1> || k_class_pred<{depth}, 2, 4, 1> (final pc_block pass per packet "
-                             "class, side by side; + k_class_count / k_class_assign)",
-                "golomb_final": "k_class_coder<2, true> (both classes; the event interval also covers the join of the side stream)",
+    if thru:  # throughput regime: every stage fills the machine, one lane per chain, predictor and Golomb work of a chain in ONE lane
+        return {"lms_search1": f"k_search1_lane<{depth}> (five mixRes pc_block passes + their dyn_comp counts in the lane)",
+                "golomb_count1": "(inside k_search1_lane)",
+                "lms_search2": f"k_search2_lane<{depth}, 2> (converge passes + numUV counts in the lane)",
+                "golomb_count2": "(inside k_search2_lane)",
+                "lms_final": f"k_class_final<{depth}, 2, 8> || k_class_final<{depth}, 2, 4> (final pc_block pass + final dyn_comp of a chain in ONE "
+                             "lane, per packet class, side by side on two streams; + k_decide2, k_class_count, k_class_assign)",
+                "golomb_final": "(inside k_class_final)",
                 "finalize_scan": "k_finalize + k_scan_sizes", "pack": "k_pack"}.get(stage, stage)
-    return {"lms_search1": "k_lms_search1", "golomb_count1": "k_gol_count1", "lms_search2": "k_lms_search2",
-            "golomb_count2": "k_gol_count2", "lms_final": "k_lms_final", "golomb_final": "k_gol_final",
-            "finalize_scan": "k_finalize + k_scan_sizes", "pack": "k_pack"}.get(stage, stage)
+    # latency regime: producer / consumer launches of 4-wave worker workgroups
+    return {"lms_search1": f"k_search1_fused<{depth}, 4, 2, true> (mixRes search passes || their dyn_comp counts, one launch of workers)",
+            "golomb_count1": "(inside k_search1_fused)",
+            "lms_search2": f"k_lms_search2_w<{depth}, 2>", "golomb_count2": "k_gol_count2_w<2>",
+            "lms_final": f"k_final_fused<{depth}, 2, 4, 2, false, true> (final pc_block pass || final dyn_comp, numUV / escape decision and "
+                         "packet sizes folded in, one launch of workers)",
+            "golomb_final": "(inside k_final_fused)",
+            "finalize_scan": "k_scan_sizes", "pack": "k_pack"}.get(stage, stage)
 
 
 def load_counters(name, key):
@@ -302,8 +300,13 @@ def encode_roofline(fmt, B, total_bytes, stage_ms, thru_hint):
             handoff[a] = ho
             fused.append(a + "+" + b)
     thru = bool(thru_hint)
-    if thru and "lms_final+golomb_final" in fused:
-        handoff["lms_final"] = 0  # predictor and coder of a chain in ONE lane: the residual never leaves the registers
+    if thru:
+        # one lane per chain does the predictor AND the Golomb work of its chain: the residuals never leave the CU, except the
+        # mixRes = 4 search pass (one of five planes), which the numUV decision reads behind the converge passes
+        for k in fused:
+            handoff[k.split("+")[0]] = 0
+        if "lms_search1+golomb_count1" in fused:
+            handoff["lms_search1"] = 2 * (res_s1 // 5)
     # stage_ms[k] = (mean ms of one launch, launches per pass).  The dominant kernel among the stages that HAVE compulsory
     # traffic (a search kernel can be the longest single launch; its §8(d) bytes are zero: no HBM roofline to carry)
     dom = max((k for k in stage_ms if algo[k] > 0), key=lambda k: stage_ms[k][0] * max(stage_ms[k][1], 1))
@@ -447,7 +450,7 @@ def rank_main(args):
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     R = max(1, args.repeats)
     fmt = alac_amd.make_format(4096, args.bit_depth, 2, 44100)

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "ALACAudioTypes.h"
@@ -28,7 +29,8 @@ static std::vector<uint8_t> slurp(const char *path)
 
 int main(int argc, char **argv)
 {
-    if (argc != 8) return 2;
+    if (argc != 8 && argc != 9) return 2;
+    const bool fast = argc == 9 && std::string(argv[8]) == "fast";  // SetFastMode(true) before InitializeEncoder
     const uint32_t bits = atoi(argv[1]), ch = atoi(argv[2]), rate = atoi(argv[3]);
     const std::vector<uint8_t> pcm = slurp(argv[4]);
     const uint32_t frames = kALACDefaultFramesPerPacket;
@@ -55,6 +57,7 @@ int main(int argc, char **argv)
     const int X = (int)(pcm.size() / inPacketBytes) + 1;
     ALACEncoder *enc = new ALACEncoder;
     enc->SetFrameSize(frames);
+    enc->SetFastMode(fast);
     if (enc->InitializeEncoder(out, X) != ALAC_noErr) return 3;
     uint32_t cookieSize = enc->GetMagicCookieSize(ch);
     std::vector<uint8_t> cookie(cookieSize);

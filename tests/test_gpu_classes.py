@@ -50,3 +50,20 @@ def test_class_path_reports_a_lost_handoff(harness, tmp_path):
                         str(tmp_path / "z.bin"), str(tmp_path / "back.pcm")], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 5, (p.returncode, p.stdout, p.stderr)
     assert not (tmp_path / "s.bin").exists()
+
+
+@pytest.mark.parametrize("bits,ch", [(16, 2), (24, 2), (16, 6)])
+def test_set_fast_mode_through_the_class(harness, oracle, tmp_path, bits, ch):
+    """ALACEncoder::SetFastMode(true) (codec/ALACEncoder.h:44): the reference tool's call sequence with the search-free path;
+    the chained stream equals the oracle's EncodeStereoFast restatement and decodes back through ALACDecoder"""
+    frames = 4096 * 4 + 77
+    pcm = music_like(frames, ch, bits, seed=bits + ch + 1)
+    (tmp_path / "in.pcm").write_bytes(pcm)
+    p = subprocess.run([harness, str(bits), str(ch), "44100", str(tmp_path / "in.pcm"), str(tmp_path / "s.bin"),
+                        str(tmp_path / "z.bin"), str(tmp_path / "back.pcm"), "fast"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    enc = oracle.encoder(4096, bits, ch, 44100, fast=True)
+    ref, ref_sizes = enc.encode_stream(np.frombuffer(pcm, np.uint8), frames, segment_packets=0)
+    assert np.array_equal(np.fromfile(tmp_path / "z.bin", np.uint32), ref_sizes)
+    assert np.array_equal(np.fromfile(tmp_path / "s.bin", np.uint8), ref)
+    assert (tmp_path / "back.pcm").read_bytes() == pcm
