@@ -71,6 +71,7 @@ AlacOptions alac_options_from_env()
     o.classFused = env_int("ALAC_HIP_CLASS_FUSED", o.classFused) != 0;
     o.searchFused = env_int("ALAC_HIP_SEARCH_FUSED", o.searchFused) != 0;
     o.fold = env_int("ALAC_HIP_FOLD", o.fold);
+    o.thruWg4 = env_int("ALAC_HIP_THRU_WG4", o.thruWg4);
     o.ldsPad = env_int("ALAC_HIP_LDS_PAD", o.ldsPad);
     o.countWalk = env_int("ALAC_HIP_COUNT_WALK", o.countWalk);
     o.initState = env_int("ALAC_HIP_INIT_STATE", o.initState) != 0;
@@ -90,7 +91,7 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask},
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
         {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
-        {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"fast_mode", &AlacOptions::fastMode}, {"lds_pad", &AlacOptions::ldsPad},
+        {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"thru_wg4", &AlacOptions::thruWg4}, {"fast_mode", &AlacOptions::fastMode}, {"lds_pad", &AlacOptions::ldsPad},
         {"debug_waves", &AlacOptions::debugWaves}, {"count_walk", &AlacOptions::countWalk},
         {"init_state", &AlacOptions::initState},
     };

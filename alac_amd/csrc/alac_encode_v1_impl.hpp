@@ -1527,14 +1527,16 @@ __device__ __forceinline__ void search2_lane_body(LmsShared<1> &sh, const uint32
         if (p2lo >= p2hi) {
             // (idleFast off: a lane whose stream ended with the converge pass must not count rows of the tail)
             golf_stream<false>(g, nTail, wave_max(nTail), chanBits, recip, one_plane(planeA + (uint64_t)p2hi * strideA, strideA, chain),
-                               NoWait(), false);
+                               NoWait(), false, false);
         } else {
             golf_stream_fn<false>(g, nTail, wave_max(nTail), chanBits, recip,
-                                  [&](uint32_t j) { return (planeA + (uint64_t)(P2 + j) * strideA)[chain]; }, NoWait(), false);
+                                  [&](uint32_t j) { return (planeA + (uint64_t)(P2 + j) * strideA)[chain]; }, NoWait(), false, false);
         }
-    } else {
-        golf_finish<false>(g, P2 > 0, recip);
     }
+    // the stream ends here whether or not it had a tail (a packet of fewer than ~80 samples has none: n8 <= P2) — a run the last
+    // counted residual left open is closed now (round 3: fuzz seeds with 17-sample frames caught a finish that only ran for
+    // lanes WITH a tail)
+    golf_finish<false>(g, P2 > 0, recip);
     if (J.active) A.cost2[(uint32_t)RS * A.chainsPad + chain] = g.bits * 8 + 16 * T;  // :438, :447 / :899
 }
 
@@ -1752,16 +1754,22 @@ __global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits,
 // Here the lane codes each 32-step tile straight from its own LDS row (where the predictor leaves the residuals in place,
 // alac_lms.hpp / lms_pass): no resC, no transposed flush, no row loads, and the wave carries two independent serial
 // recurrences (sign-LMS and the Golomb mean tracker) instead of one.
-template <int DEPTH, int CH, int T>
-__global__ __launch_bounds__(64, 2) void k_class_final(V1Args A, uint32_t chanBits, uint32_t region)
+// WG = 1: single-wave workgroups; WG = 4: workgroups of four workers (worker_id): every workgroup puts exactly one wave on each
+// SIMD of its CU, so the SIMDs of a CU carry equal numbers of these equally long waves whatever the CU's wave allocator does
+template <int DEPTH, int CH, int T, int WG = 1>
+__global__ __launch_bounds__(64 * WG, 2) void k_class_final(V1Args A, uint32_t chanBits, uint32_t region)
 {
-    __shared__ LmsShared<1> sh;
-    __shared__ uint32_t recip[17];
-    const int lane = threadIdx.x;
+    __shared__ LmsShared<1> shAll[WG];
+    __shared__ uint32_t recipAll[WG][20];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wslot = threadIdx.x >> 6, wid = blockIdx.x * (uint32_t)WG + wslot;
+    LmsShared<1> &sh = shAll[wslot];
+    uint32_t *recip = recipAll[wslot];
     const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
-    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * 64u;
+    const uint32_t col0 = (region ? base4 : 0u) + wid * 64u;
     if (col0 >= (region ? nCols : base4)) return;
     gol_table_init(recip, lane);
+    lds_order();
     ChainJob J;
     int best;
     const uint32_t col = col0 + (uint32_t)lane;
@@ -1994,8 +2002,13 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 }
                 if (opt.classFused) {
                     // predictor and coder of a chain in one lane: no residual plane (k_class_final)
-                    hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
-                    hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                    if (opt.thruWg4) {
+                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8, 4>), dim3((cwaves + 3) / 4), dim3(256), 0, sp, A, chanBits, 0u);
+                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4, 4>), dim3((cwaves + 3) / 4), dim3(256), 0, s2, A, chanBits, 1u);
+                    } else {
+                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
+                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                    }
                     if (two) {
                         (void)hipEventRecord(vs.join[0], s2);
                         (void)hipStreamWaitEvent(sh, vs.join[0], 0);

@@ -3,8 +3,9 @@
 // lockstep over the sample index.
 //
 // What differs from the plain restatement in alac_dev.hpp (same bits out):
-//   * n / m with m = 2^k - 1 is a multiply-high by a tabulated reciprocal ceil(2^32 / m): exact whenever
-//     n * m < 2^32, which holds on the only branch that uses the quotient (n < 9 m, k <= 14);
+//   * the symbol's quotient n / m with m = 2^k - 1 is table-free: two shift-and-add levels (golf_sym), exact on the only
+//     branch that uses it (n < 9 m); only the rare run-length code (golf_close_run) still takes a multiply-high by the
+//     tabulated reciprocal ceil(2^32 / m) — exact there because nz < 2^16 and m < 2^8;
 //   * pb is the encoder's constant 40 (= (pbFactor 4 * PB0 40) / 4, codec/ALACEncoder.cu:365,515), so
 //     pb * x is two shifts and an add instead of a quarter-rate 32-bit multiply;
 //   * "numBits > 25 -> escape" (ag_enc.c:167) cannot fire for kb <= 14 (div <= 8, k <= 14) and is dropped.
@@ -363,7 +364,8 @@ __device__ __forceinline__ void golf_stream(GolF &g, uint32_t n, uint32_t nMaxWa
 // functor form (any per-lane row choice), used only where lanes of one wave disagree about the planes
 template <bool WRITE, class Fetch, class Need = NoWait>
 __device__ __forceinline__ void golf_stream_fn(GolF &g, uint32_t n, uint32_t nMaxWave, uint32_t bitSize,
-                                            const uint32_t *recip, Fetch &&fetch, Need &&need = Need(), bool idleFast = true)
+                                            const uint32_t *recip, Fetch &&fetch, Need &&need = Need(), bool idleFast = true,
+                                            bool finish = true)
 {
     constexpr int B = 16;
     int32_t bufA[B], bufB[B], bufC[B];
@@ -397,7 +399,9 @@ __device__ __forceinline__ void golf_stream_fn(GolF &g, uint32_t n, uint32_t nMa
         load(bufB, jb + 4 * B);
         code(bufC, jb + 2 * B);
     }
-    golf_finish<WRITE>(g, n > 0, recip);
+    const uint32_t openRun = g.inrun;
+    golf_finish<WRITE>(g, n > 0 && finish, recip);
+    if (!finish) g.inrun = openRun;  // the caller finishes the stream
 }
 
 }  // namespace alacdev

@@ -107,6 +107,7 @@ struct AlacOptions {
     int32_t debugWaves = 0;    // "debug_waves"  wave placement / timing stamps of the fused final launch into the workspace (tools/wave_map.py)
     int32_t ldsPad = 0;        // "lds_pad"      ALAC_HIP_LDS_PAD     dynamic LDS bytes added to the single-wave workgroups of the fused final
                                //                                     launch (caps the workgroups a CU takes: experiments)
+    int32_t thruWg4 = 0;       // "thru_wg4"     ALAC_HIP_THRU_WG4    throughput regime: the class launches as 4-worker workgroups
     int32_t fastMode = 0;      // "fast_mode"    (no env)             ALACEncoder::SetFastMode: stereo elements without the search (EncodeStereoFast)
     int32_t fold = 6;          // "fold"         ALAC_HIP_FOLD        latency regime: converge passes || counts in one launch, decision and
                                //                                     packet sizes inside the final launch, no k_init_state / k_decide* / k_finalize

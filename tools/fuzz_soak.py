@@ -1,5 +1,6 @@
 """One-off soak of tests/test_gpu_fuzz.py's randomised parity case with seeds beyond the 48 the suite runs:
-    python tools/fuzz_soak.py FIRST LAST     (GPU box; every seed: GPU packets == oracle packets, decode == input)"""
+    python tools/fuzz_soak.py FIRST LAST ["k=v,k=v"]    (GPU box; every seed: GPU packets == oracle packets, decode == input;
+                                                         the optional third argument pins context options, e.g. "thru=1")"""
 import os
 import sys
 
@@ -15,6 +16,11 @@ import test_gpu_fuzz as fz  # noqa: E402
 def main():
     first, last = int(sys.argv[1]), int(sys.argv[2])
     ctx, oracle = alac_amd.Context(0), Oracle()
+    if len(sys.argv) > 3:
+        for kv in sys.argv[3].split(","):
+            if kv:
+                ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        print("options", sys.argv[3], flush=True)
     case = fz.test_random_layouts_match_oracle_and_round_trip
     case = getattr(case, "__wrapped__", case)
     bad = 0
