@@ -690,6 +690,10 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
     if (timed && ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size())
         ev = &ctx->events[ctx->profCalls++ * EV];
     hipError_t e;
+    // the caller's bound on the segment length (alac_hip_encode_segmented) is checked on the device whatever kernels run
+    if (d_seg_first && maxSegHint)
+        launch_check_segments(d_seg_first, num_segments, num_packets, maxSegHint < num_packets ? maxSegHint : num_packets,
+                              ctx->errDev ? ctx->errDev + 1 : nullptr, ctx->stream);
     if (use_lane_encoder(ctx)) {
         if (ev) ctx->profSub.push_back(0);
         e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream,
@@ -713,7 +717,6 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
             // the caller knows how long its longest segment is (alac_hip_encode_segmented): no read-back of the table, no
             // host wait.  The bound is checked on the device; a table that contradicts it fails the next synchronize.
             maxSeg = maxSegHint < num_packets ? maxSegHint : num_packets;
-            launch_check_segments(d_seg_first, num_segments, num_packets, maxSeg, ctx->errDev ? ctx->errDev + 1 : nullptr, ctx->stream);
         } else if (d_seg_first) {
             std::vector<uint32_t> sf(num_segments + 1);
             if (hipMemcpyAsync(sf.data(), d_seg_first, (num_segments + 1) * 4ull, hipMemcpyDeviceToHost, ctx->stream) !=
