@@ -29,8 +29,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel-name substring -> bench.py stage name
 STAGE_OF = [
-    ("k_search1_fused", "lms_search1"), ("k_lms_search1", "lms_search1"), ("k_gol_count1", "golomb_count1"),
-    ("k_search2_fused", "lms_search2"), ("k_lms_search2", "lms_search2"), ("k_gol_count2", "golomb_count2"),
+    ("k_search1_fused", "lms_search1"), ("k_search1_lane", "lms_search1"), ("k_lms_search1", "lms_search1"),
+    ("k_gol_count1", "golomb_count1"),
+    ("k_search2_fused", "lms_search2"), ("k_search2_lane", "lms_search2"), ("k_lms_search2", "lms_search2"),
+    ("k_gol_count2", "golomb_count2"), ("k_decide_fast", "lms_final"),
     ("k_init_state", "lms_search1"), ("k_decide1", "lms_search2"), ("k_decide2", "lms_final"),
     ("k_final_fused", "lms_final"), ("k_lms_final", "lms_final"), ("k_gol_final", "golomb_final"),
     ("k_class_count", "lms_final"), ("k_class_assign", "lms_final"), ("k_class_pred", "lms_final"),
