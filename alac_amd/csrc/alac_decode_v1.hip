@@ -349,7 +349,7 @@ struct EntLane {
 // packets: 4.1 ms with the stores, 2.8 ms without them).  Here a round only RECORDS (position, value) per symbol; the
 // stores are issued at the start of the next round, right after the wait, and have a whole round to complete.  A symbol
 // that was not decoded repeats the lane's previous pair (same value to the same address: harmless).
-template <bool PB40, bool PUB, bool WIDE = false>
+template <bool PB40, bool PUB, bool WIDE = false, bool ZFILL = WIDE>
 __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, uint32_t *ringRow, uint64_t wordBase,
                                                uint32_t cur0, uint32_t bit0, uint32_t limit, uint64_t nbytes,
                                                uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV,
@@ -415,14 +415,33 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         dpos[k] = 0;
         dval[k] = 0;
     }
-    bool had = false;  // this lane decoded something in the round the pairs come from
+    bool had = false;   // this lane decoded something in the round the pairs come from
+    bool full = false;  // ... and decoded its last symbol (so all of them)
+    // A lane that stops decoding inside a round stays stopped (and repeats its last pair), and positions only grow: when the
+    // LAST symbol of the round was decoded all sixteen were, and "last - first == 15" then means sixteen CONSECUTIVE
+    // residuals — every round of a lane outside zero runs.  Those leave as four 16-byte stores instead of sixteen 4-byte ones: the 64 lanes of a store instruction hit 64
+    // different cache lines either way, and it is the number of such instructions that the CU's one address path serialises.
     auto store_deferred = [&]() {
         if constexpr (WIDE) {
-            if (storer && had) {
+            typedef int32_t I4 __attribute__((ext_vector_type(4), aligned(4)));
+            const bool mine = storer && had;
+            const bool run16 = mine && full && dpos[kDecRound - 1] - dpos[0] == (uint32_t)(kDecRound - 1);
+            if (run16) {
+                int32_t *dst = rowBase + dpos[0];
 #pragma unroll
-                for (int k = 0; k < kDecRound; k++) rowBase[dpos[k]] = dval[k];
+                for (int k = 0; k < kDecRound; k += 4) {
+                    I4 t = {dval[k], dval[k + 1], dval[k + 2], dval[k + 3]};
+                    *(I4 *)(dst + k) = t;
+                }
+            }
+            if (__any(mine && !run16)) {
+                if (mine && !run16) {
+#pragma unroll
+                    for (int k = 0; k < kDecRound; k++) rowBase[dpos[k]] = dval[k];
+                }
             }
             had = false;
+            full = false;
         }
     };
     while (__any(E.active != 0)) {
@@ -475,6 +494,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                     lastPos = rowOff + E.c;
                     lastVal = val;
                     had = true;
+                    full = it == kDecRound - 1;
                     dpos[it] = lastPos;
                     dval[it] = val;
                 }
@@ -485,8 +505,11 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                 E.zmode = 0;
                 const bool zrun = ((mb << 2) < (1u << kQBShift)) && (E.c < numSamples) && E.active;
                 if (__any(zrun || E.c >= numSamples)) {
+                    int32_t *zfAt = nullptr;  // ZFILL: where this lane's run of zfCnt zeros starts
+                    uint32_t zfCnt = 0;
                     if (zrun) {
-                        // zero run (ag_dec.c:324-352): the plane is pre-zeroed, only the index moves
+                        // zero run (ag_dec.c:324-352): only the index moves (the plane is pre-zeroed, or — ZFILL — the zeros
+                        // are written right behind this block)
                         E.zmode = 1;
                         const uint32_t kz = (uint32_t)(lead(mb) - 24 + (int32_t)((mb + 16u) >> 6));
                         const uint32_t mz = ((1u << kz) - 1) & wb;
@@ -509,10 +532,38 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                         if (!((uint64_t)E.c + nz <= (uint64_t)numSamples)) {  // :341
                             E.status = -50;
                             E.active = 0;
+                        } else if constexpr (ZFILL) {
+                            zfAt = rowBase + rowOff + E.c;
+                            zfCnt = nz;
                         }
                         E.c += nz;
                         if (nz >= 65535) E.zmode = 0;
                         E.mb = 0;
+                    }
+                    if constexpr (ZFILL) {
+                        // This launch does not clear the plane first (a 4.1 GB fill at 125 000 stereo packets):
+                        // the zeros of a run are written here, by the WHOLE wave for one lane's run at a time — 1 KB per store
+                        // instruction (lane-by-lane, a silent channel alone was 1024 serial 16-byte stores of one lane).
+                        typedef int32_t I4 __attribute__((ext_vector_type(4), aligned(4)));
+                        const I4 zero4 = {0, 0, 0, 0};
+                        // (this is inside the per-lane "decode a symbol" branch: only the lanes still decoding are here)
+                        const uint64_t here = __ballot(1);
+                        const uint32_t nHere = (uint32_t)__popcll(here);
+                        const uint32_t rank = (uint32_t)__popcll(here & ((1ull << (threadIdx.x & 63)) - 1));
+                        for (uint64_t m = __ballot(zfCnt != 0); m; m &= m - 1) {
+                            const int src = __builtin_ctzll(m);
+                            const uint64_t at = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)zfAt >> 32), src) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)zfAt, src);
+                            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)zfCnt, src);
+                            int32_t *z = (int32_t *)at;
+                            for (uint32_t i = rank * 4; i < cnt; i += nHere * 4) {
+                                if (i + 4 <= cnt) {
+                                    *(I4 *)(z + i) = zero4;
+                                } else {
+                                    for (uint32_t q = i; q < cnt; q++) z[q] = 0;
+                                }
+                            }
+                        }
                     }
                     if (E.active && E.c >= numSamples) {
                         // channel complete: ag_dec.c:359 end check; the next channel starts where this one ended
@@ -542,7 +593,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
     publish();  // everything is complete (or failed): nobody waits for this lane any more
 }
 
-template <bool PUB, bool WIDE = false>
+template <bool PUB, bool WIDE = false, bool ZFILL = WIDE>
 __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block)
 {
     const DecodeArgs &A = V.d;
@@ -605,9 +656,9 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
 
     uint32_t *prog = (PUB && live) ? V.prog + (uint64_t)p * 2 : nullptr;
     if (__all(!coded || (pbU == 40 && pbV == 40)))
-        entropy_rounds<true, PUB, WIDE>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<true, PUB, WIDE, ZFILL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
     else
-        entropy_rounds<false, PUB, WIDE>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<false, PUB, WIDE, ZFILL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
 
     if (live && E.status != status0) {
         rec->status = E.status;
@@ -1033,7 +1084,8 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
             typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
             const uint32_t n4 = n & ~3u;
             for (uint32_t j = ((blockIdx.x % bx) * blockDim.x + threadIdx.x) * 4; j < n4; j += bx * blockDim.x * 4) {
-                const I4 uu = *(const I4 *)(u + j), vv = *(const I4 *)(v + j);
+                const I4 zz = {0, 0, 0, 0};
+                const I4 uu = absent ? zz : *(const I4 *)(u + j), vv = absent ? zz : *(const I4 *)(v + j);
                 U4 o;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1051,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
             }
             // the last n mod 4 frames of a short packet
             for (uint32_t j = n4 + (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
-                const int32_t uu = u[j], vv = v[j];
+                const int32_t uu = absent ? 0 : u[j], vv = absent ? 0 : v[j];
                 int32_t l, r;
                 if (mixRes != 0) {
                     l = uu + vv - ((mixRes * vv) >> mixBits);
@@ -1068,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
     for (uint32_t j = (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
         int32_t l, r = 0;
         if constexpr (CH == 2) {
-            const int32_t uu = u[j], vv = v[j];
+            const int32_t uu = absent ? 0 : u[j], vv = absent ? 0 : v[j];
             if (mixRes != 0) {
                 l = uu + vv - ((mixRes * vv) >> mixBits);
                 r = l - vv;
@@ -1077,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
                 r = vv;
             }
         } else {
-            l = u[j];
+            l = absent ? 0 : u[j];
         }
         if (shb != 0 && DEPTH >= 24) {
             const uint8_t *base = A.stream + A.offsets[p];
@@ -1125,7 +1177,13 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSi
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(sc, side->fork, 0);
     }
-    (void)hipMemsetAsync(V.plane, 0, planeBytes, sc);  // zero runs only move the index (k_dec_entropy)
+    // zero runs only move the index (k_dec_entropy, fused launch) — except in k_dec_entropy_wide, which writes the zeros of its
+    // runs itself (in the fused launch the same code made the entropy wave, the launch's serial chain, slower than the 50 us
+    // fill it saves: 10 000 packets 1.95 -> 2.14 ms):
+    // every sample a later kernel reads is then written by somebody (coded rows: residuals + run zeros; uncompressed rows:
+    // k_dec_raw; absent elements of a > 2-channel round: k_dec_unmix reads nothing), and the fill is left out
+    const bool zerosWritten = !fused0 && V.d.optWide != 0;
+    if (!zerosWritten) (void)hipMemsetAsync(V.plane, 0, planeBytes, sc);
     if (useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, sc);
     if (V.mismatch) (void)hipMemsetAsync(V.mismatch, 0, 4, st);
     if (stageFirst)
@@ -1157,10 +1215,11 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSi
         // classes) must not all land on the same few workgroups
         hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4093u ? da.numPackets : 4093u), dim3(256), 0, st, V);
         const bool wide = V.d.optWide != 0;
-        // deferred residual stores pay while a SIMD holds at most two entropy waves (measured, entropy kernel alone: 60 000
-        // packets 3.19 -> 2.51 ms, 125 000 4.06 -> 3.82, but 250 000 6.36 -> 6.86: with more waves per SIMD the other
-        // waves already cover the store round trips and the extra instructions only cost)
-        if (wide && nEnt <= 2048)
+        // deferred residual stores, four 16-byte stores per round of sixteen consecutive residuals (round 2, 4-byte stores:
+        // paid only up to two entropy waves per SIMD; with the wide stores, measured whole decode pass at 125 000 / 250 000 /
+        // 500 000 packets: 9.31 -> 8.19, 19.4 -> 14.2, 38.1 -> 26.5 ms — the kernel was bound by the number of store
+        // instructions whose 64 lanes hit 64 different cache lines, which a CU's address path takes one line at a time)
+        if (wide)
             hipLaunchKernelGGL(k_dec_entropy_wide, dim3(nEnt), dim3(64), 0, st, V);
         else
             hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
