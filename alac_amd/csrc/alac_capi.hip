@@ -64,6 +64,7 @@ AlacOptions alac_options_from_env()
     if (const char *e = getenv("ALAC_HIP_DECODER")) o.laneDecoder = strcmp(e, "lane") == 0;
     if (const char *e = getenv("ALAC_HIP_DEC_FUSED")) o.decFused = *e ? (e[0] == '0' ? 0 : 1) : -1;
     o.decWide = env_int("ALAC_HIP_DEC_WIDE", o.decWide) != 0;
+    o.decPair = env_int("ALAC_HIP_DEC_PAIR", o.decPair) != 0;
     o.decPubMask = env_int("ALAC_HIP_DEC_PUBMASK", o.decPubMask);
     o.stageTaps = env_int("ALAC_HIP_STAGE_TAPS", o.stageTaps) != 0;
     o.loseHandoff = env_int("ALAC_HIP_DEBUG_LOSE_HANDOFF", o.loseHandoff) == 1;
@@ -88,7 +89,7 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"overlap_pos", &AlacOptions::overlapPos}, {"fused", &AlacOptions::fused},
         {"subbatch", &AlacOptions::subBatch},   {"encoder_lane", &AlacOptions::laneEncoder},
         {"decoder_lane", &AlacOptions::laneDecoder}, {"dec_fused", &AlacOptions::decFused},
-        {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask},
+        {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask}, {"dec_pair", &AlacOptions::decPair},
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
         {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
         {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"thru_wg4", &AlacOptions::thruWg4}, {"fast_mode", &AlacOptions::fastMode}, {"lds_pad", &AlacOptions::ldsPad},
@@ -346,8 +347,8 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets, uint64_t str
     off = align_up(off + (uint64_t)numPackets * L.maxElems * sizeof(DecRec), 256);
     L.resid = off;
     off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
-    L.prog = off;  // progress words of the fused launch / chain list + two counters of the separate launches
-    off = align_up(off + (uint64_t)numPackets * 8 + 8, 256);
+    L.prog = off;  // progress words of the fused launch / chain list, counters and pair list of the separate launches
+    off = align_up(off + (uint64_t)numPackets * 12 + 64, 256);
     L.elemBit = off;
     off = align_up(off + (uint64_t)numPackets * 4, 256);
     L.mismatch = off;
@@ -953,6 +954,7 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.ho = handoff_ctl(ctx);
     da.optFused = ctx->opt.decFused;
     da.optWide = ctx->opt.decWide;
+    da.optPair = ctx->opt.decPair;
     da.optPubMask = (uint32_t)ctx->opt.decPubMask;
     hipError_t e;
     if (use_lane_decoder(ctx)) {

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         rec->shiftPos = R.shiftPos;
         rec->status = status;
         rec->pad = (uint32_t)hpos;  // first payload bit (entropy coded or raw), from the packet start
+        rec->pad2 = 0;              // set by k_dec_classify where the predictor lanes write the packet's PCM themselves
         A.statusOut[p] = status;
         if (V.mismatch && status == -4) atomicAdd(V.mismatch, 1u);  // gates the lane decoder behind this pipeline
         if (V.round == 0 || haveElement || status != 0) A.numSamplesOut[p] = status == 0 ? R.numSamples : 0;
@@ -843,22 +844,58 @@ __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_b
 // and a wave walks 64 chains.  k_dec_classify sorts the chains the fast path accepts by tap count into ONE list filled
 // from both ends (4-tap chains from the front, 8-tap chains from the back; it lives in the progress words of the fused
 // launch, which this regime does not use; the two counters sit behind them).
+// Pair mode (16-bit stereo into a stereo frame, the shape of the benchmark and of most files): a packet whose two chains
+// both take the fast path is listed as a PAIR instead — class A (4 + 4 taps) from the front of the pair list, class B
+// (anything with an 8-tap chain) from its back — and its chains sit in adjacent lanes of unpc_pair_body, which un-mixes
+// and writes the PCM itself; the record's pad2 tells k_dec_unmix to leave that packet alone.
+// prog layout here: [0, 2n) chain list | [2n, 2n + 16) counters c4, c8, pA, pB | [2n + 16, 3n + 16) pair list
+constexpr uint32_t kDecCounters = 16;
+__device__ __host__ inline bool dec_pair_mode(const DecV1Args &V)
+{
+    return V.d.bitDepth == 16 && V.d.numChannels == 2 && V.outChannels == 2 && V.elemBit == nullptr && V.d.optPair != 0;
+}
+
 __global__ __launch_bounds__(256) void k_dec_classify(DecV1Args V)
 {
     const DecodeArgs &A = V.d;
     const uint32_t total = A.numPackets * A.numChannels;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool pairMode = dec_pair_mode(V);
     bool ok = false, wide = false;
+    uint32_t p = 0, ch = 0;
     if (gid < total) {
-        const uint32_t p = gid / A.numChannels, ch = gid % A.numChannels;
+        p = gid / A.numChannels, ch = gid % A.numChannels;
         const DecRec *rec = A.recs + p;
         ok = unpc_fast_ok(A, rec, ch);
         wide = ok && rec->c[ch].num == 8;
     }
     uint32_t *list = V.prog, *cnt = V.prog + 2 * (uint64_t)A.numPackets;
-    const uint64_t m4 = __ballot(ok && !wide), m8 = __ballot(wide);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t below = (1ull << lane) - 1;
+    bool pairA = false, pairB = false;
+    if (pairMode) {
+        // the two chains of a packet are the lanes 2k, 2k + 1 of this wave (gid = 2 p + ch, 256 threads per workgroup)
+        const bool okO = __shfl_xor((int)ok, 1) != 0, wideO = __shfl_xor((int)wide, 1) != 0;
+        const bool both = ok && okO && A.recs[p].elementChannels == 2;
+        if (both) {
+            pairA = ch == 0 && !wide && !wideO;
+            pairB = ch == 0 && (wide || wideO);
+            ok = wide = false;  // not in the chain lists
+            if (ch == 0) A.recs[p].pad2 = 1;
+        }
+        uint32_t *pairs = cnt + kDecCounters;
+        const uint64_t mA = __ballot(pairA), mB = __ballot(pairB);
+        uint32_t bA = 0, bB = 0;
+        if (lane == 0) {
+            if (mA) bA = atomicAdd(cnt + 2, (uint32_t)__popcll(mA));
+            if (mB) bB = atomicAdd(cnt + 3, (uint32_t)__popcll(mB));
+        }
+        bA = (uint32_t)__shfl((int)bA, 0);
+        bB = (uint32_t)__shfl((int)bB, 0);
+        if (pairA) pairs[bA + (uint32_t)__popcll(mA & below)] = p;
+        if (pairB) pairs[A.numPackets - 1 - (bB + (uint32_t)__popcll(mB & below))] = p;
+    }
+    const uint64_t m4 = __ballot(ok && !wide), m8 = __ballot(wide);
     uint32_t b4 = 0, b8 = 0;
     if (lane == 0) {
         if (m4) b4 = atomicAdd(cnt, (uint32_t)__popcll(m4));
@@ -907,13 +944,12 @@ __device__ __forceinline__ int32_t lms_step_dec_wide(int32_t (&a)[T], int32_t (&
 }
 
 template <int T>
-__global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
+__device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, uint32_t block, uint32_t count)
 {
     const DecodeArgs &A = V.d;
     const uint32_t total = A.numPackets * A.numChannels;
-    const uint32_t count = V.prog[2 * (uint64_t)A.numPackets + (T == 8 ? 1 : 0)];
-    if (blockIdx.x * 64u >= count) return;
-    const uint32_t idx = blockIdx.x * 64u + threadIdx.x;
+    if (block * 64u >= count) return;
+    const uint32_t idx = block * 64u + threadIdx.x;
     const bool active = idx < count;
     const uint32_t chain = active ? (T == 8 ? V.prog[total - 1 - idx] : V.prog[idx]) : 0;
     const uint32_t p = chain / A.numChannels, ch = chain % A.numChannels;
@@ -998,6 +1034,197 @@ __global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
     }
 }
 
+// ---- pair mode: the two chains of a stereo packet in adjacent lanes; the lanes un-mix and write the PCM themselves ----
+// T = 4: both chains have 4 taps.  T = 8: at least one has 8; a 4-tap chain then lives in an 8-tap lane with dead upper
+// taps: their coefficients start at 0 and stay there (the sign of b is forced to 0, so t = 0 and nothing is added), the
+// "top" sample is the one five back instead of nine, and the threshold weights are na - i with the lane's own na.
+template <int T>
+__device__ __forceinline__ int32_t lms_step_dec_pair(int32_t (&a)[T], int32_t (&w)[T], int32_t &tp, int32_t del, uint32_t chanbits,
+                                                     bool is4, int32_t act, const uint32_t (&wg)[4])
+{
+    int32_t b[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) b[i] = tp - w[i];
+    int32_t s = 255;
+#pragma unroll
+    for (int i = 0; i < T; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;
+    const int32_t out = __builtin_amdgcn_sbfe(del + tp - (s >> kDenShift), 0, chanbits);
+    const int32_t nd = -del;
+    const int32_t adel = max(del, nd);
+    const int32_t nsg = sign3(nd);
+    const int32_t rc = (del >> 31) & ((1 << kDenShift) - 1);
+    int32_t sb[T];
+    uint32_t t[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        sb[i] = sign3(b[i]);
+        if (T == 8 && i >= 4) sb[i] &= act;
+        t[i] = (uint32_t)(__mul24(sb[i], b[i]) + rc) >> kDenShift;
+    }
+    int32_t S[T];
+    S[T - 1] = 0;
+#pragma unroll
+    for (int i = T - 1; i > 0; i--) {
+        const uint32_t weight = T == 4 ? (uint32_t)(T - i) : (i < 4 ? wg[i] : (uint32_t)(T - i));
+        S[i - 1] = (int32_t)__umul24(t[i], weight) + S[i];
+    }
+#pragma unroll
+    for (int i = 0; i < T; i++) a[i] = __mul24(adel > S[i] ? nsg : 0, sb[i]) + a[i];
+    tp = T == 4 ? w[3] : (is4 ? w[3] : w[7]);
+#pragma unroll
+    for (int i = T - 1; i > 0; i--) w[i] = w[i - 1];
+    w[0] = out;
+    return out;
+}
+
+template <int T>
+__device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t block, uint32_t count)
+{
+    const DecodeArgs &A = V.d;
+    if (block * 32u >= count) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t idx = block * 32u + lane / 2, ch = lane & 1;
+    const bool active = idx < count;
+    const uint32_t *pairs = V.prog + 2 * (uint64_t)A.numPackets + kDecCounters;
+    const uint32_t p = active ? (T == 8 ? pairs[A.numPackets - 1 - idx] : pairs[idx]) : 0;
+    const DecRec *rec = A.recs + p;
+    const uint32_t n = active ? rec->numSamples : 0;
+    const uint32_t chanbits = A.bitDepth - (active ? rec->bytesShifted : 0) * 8 + 1;
+    const bool is4 = T == 4 || !active || rec->c[ch].num == 4;
+    const int32_t act = is4 ? 0 : -1;
+    uint32_t wg[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) wg[i] = (is4 ? 4u : 8u) - (uint32_t)i;
+    const int32_t mixRes = active ? rec->mixRes : 0, mixBits = active ? rec->mixBits : 0;
+    const int32_t mixMask = mixRes != 0 ? -1 : 0;
+    const bool isU = ch == 0;
+    int32_t *row = V.plane + ((uint64_t)p * 2 + ch) * A.frameSize;
+    uint32_t *pcm = (uint32_t *)(A.pcmOut + (uint64_t)p * A.frameSize * 4);  // one word per frame: L | R << 16
+
+    // K outputs of each lane of a pair -> K frames: the U lane takes the first K / 2 frames, the V lane the rest; one DPP
+    // exchange per frame hands each lane the sample of the other channel it needs (gpu_unmix16, codec/ALACDecoder.cu:193-223)
+    typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+    auto emit = [&](auto &o, auto kc, uint32_t jb) {
+        constexpr int K = decltype(kc)::value;
+        uint32_t word[K / 2];
+#pragma unroll
+        for (int k = 0; k < K / 2; k++) {
+            const int32_t give = isU ? o[k + K / 2] : o[k];
+            const int32_t recv = dpp_xor1(give);
+            const int32_t mine = isU ? o[k] : o[k + K / 2];
+            const int32_t uu = isU ? mine : recv, vv = isU ? recv : mine;
+            const int32_t l = uu + ((vv - ((mixRes * vv) >> mixBits)) & mixMask);
+            const int32_t r = mixRes != 0 ? l - vv : vv;
+            word[k] = __builtin_amdgcn_perm((uint32_t)r, (uint32_t)l, 0x05040100u);
+        }
+        const uint32_t f0 = jb + (isU ? 0u : (uint32_t)(K / 2));
+#pragma unroll
+        for (int q = 0; q < K / 8; q++) {
+            const uint32_t f = f0 + 4 * q;
+            if (active && f + 4 <= n) {
+                const U4 t4 = {word[4 * q], word[4 * q + 1], word[4 * q + 2], word[4 * q + 3]};
+                *(U4 *)(pcm + f) = t4;
+            } else if (active && f < n) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (f + e < n) pcm[f + e] = word[4 * q + e];
+            }
+        }
+    };
+
+    // ---- head: the first 16 samples lane-serially, with the lane's own tap count ----
+    int32_t d16[16], o16[16], a8[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int4 t = active ? ((const int4 *)row)[q] : make_int4(0, 0, 0, 0);
+        d16[4 * q] = t.x;
+        d16[4 * q + 1] = t.y;
+        d16[4 * q + 2] = t.z;
+        d16[4 * q + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) a8[k] = (active && k < (is4 ? 4 : 8)) ? (int32_t)rec->c[ch].coefs[k] : 0;
+    if constexpr (T == 4) {
+        unpc_head16<4>(d16, o16, a8, 32 - chanbits);
+    } else {
+        int32_t o4[16], c4[8], o8[16], c8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) c4[k] = c8[k] = a8[k];
+        unpc_head16<4>(d16, o4, c4, 32 - chanbits);
+        unpc_head16<8>(d16, o8, c8, 32 - chanbits);
+#pragma unroll
+        for (int k = 0; k < 16; k++) o16[k] = is4 ? o4[k] : o8[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) a8[k] = is4 ? (k < 4 ? c4[k] : 0) : c8[k];
+    }
+    emit(o16, std::integral_constant<int, 16>{}, 0);
+    int32_t a[T], w[T];
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+        a[i] = a8[i];
+        w[i] = o16[15 - i];
+    }
+    int32_t tp = T == 4 ? o16[11] : (is4 ? o16[11] : o16[7]);
+
+    const uint32_t nMax = wave_max_u32(n);
+    auto load32 = [&](uint32_t jb, int32_t (&d)[32]) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int4 t = *(const int4 *)(row + jb + 4 * q);
+            d[4 * q] = t.x;
+            d[4 * q + 1] = t.y;
+            d[4 * q + 2] = t.z;
+            d[4 * q + 3] = t.w;
+        }
+    };
+    int32_t dA[32], dB[32];
+    if (32 < nMax) load32(32, dA);
+    if (16 < nMax) {
+        int32_t d[16], o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int4 t = *(const int4 *)(row + 16 + 4 * q);
+            d[4 * q] = t.x;
+            d[4 * q + 1] = t.y;
+            d[4 * q + 2] = t.z;
+            d[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) o[s2] = lms_step_dec_pair<T>(a, w, tp, d[s2], chanbits, is4, act, wg);
+        emit(o, std::integral_constant<int, 16>{}, 16);
+    }
+    auto step32 = [&](uint32_t jb, const int32_t (&cur)[32], int32_t (&nxt)[32]) {
+        if (jb + 32 < nMax) load32(jb + 32, nxt);
+        int32_t o[32];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) o[s2] = lms_step_dec_pair<T>(a, w, tp, cur[s2], chanbits, is4, act, wg);
+        emit(o, std::integral_constant<int, 32>{}, jb);
+    };
+    for (uint32_t jb = 32; jb < nMax; jb += 64) {
+        step32(jb, dA, dB);
+        if (jb + 32 < nMax) step32(jb + 32, dB, dA);
+    }
+}
+
+// ONE launch for both lists: the 8-tap waves (the longer chains) take the first workgroups, the 4-tap waves the ones behind.
+// As two launches, one after the other, each ran at about two waves per SIMD (2 266 and 1 640 waves at 125 000 stereo
+// packets) and was as slow as its own serial chain: 1.65 + 1.29 ms.
+// (pair mode: class-B pairs, 8-tap chains, class-A pairs, 4-tap chains)
+__global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
+{
+    const uint32_t *cnt = V.prog + 2 * (uint64_t)V.d.numPackets;
+    const uint32_t c4 = cnt[0], c8 = cnt[1], pA = cnt[2], pB = cnt[3];
+    const uint32_t nbB = (pB + 31u) / 32u, nb8 = (c8 + 63u) / 64u, nbA = (pA + 31u) / 32u;
+    uint32_t b = blockIdx.x;
+    if (b < nbB) return unpc_pair_body<8>(V, b, pB);
+    b -= nbB;
+    if (b < nb8) return unpc_wide_body<8>(V, b, c8);
+    b -= nb8;
+    if (b < nbA) return unpc_pair_body<4>(V, b, pA);
+    b -= nbA;
+    unpc_wide_body<4>(V, b, c4);
+}
+
 // ---- fused launch: a launch of WORKERS (waves), four to a workgroup with consecutive worker ids, so that the waves of a
 // workgroup get a SIMD each by construction (as single-wave workgroups their SIMD was up to whatever state the launches
 // before had left in the CU's wave allocator: see alac_encode_v1_impl.hpp, worker_id).  The entropy waves are the launch's
@@ -1065,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
     const uint32_t bx = blocks_per_packet(A.frameSize);
     const uint32_t p = blockIdx.x / bx;
     const DecRec *rec = A.recs + p;
-    if (rec->status != 0) return;
+    if (rec->status != 0 || rec->pad2 != 0) return;  // pad2: unpc_pair_body wrote this packet's PCM
     // element rounds: a packet that ended before this element leaves these channels zero (codec/ALACDecoder.cu:971-998)
     const bool absent = V.elemBit && rec->elementChannels == 0;
     const uint32_t n = absent ? (V.round ? A.numSamplesOut[p] : A.frameSize) : rec->numSamples;
@@ -1225,10 +1452,9 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSi
             hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
         if (wide) {
             // chains sorted by tap count, one lane per chain (ALAC_HIP_DEC_WIDE=0: the two-lane kernel of the fused launch)
-            (void)hipMemsetAsync(V.prog + 2 * (uint64_t)da.numPackets, 0, 8, st);
+            (void)hipMemsetAsync(V.prog + 2 * (uint64_t)da.numPackets, 0, kDecCounters * 4, st);
             hipLaunchKernelGGL(k_dec_classify, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, V);
-            hipLaunchKernelGGL(k_dec_unpc_wide<4>, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
-            hipLaunchKernelGGL(k_dec_unpc_wide<8>, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
+            hipLaunchKernelGGL(k_dec_unpc_wide, dim3((uint32_t)((lanes + 63) / 64) + 4), dim3(64), 0, st, V);
         } else {
             hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
         }

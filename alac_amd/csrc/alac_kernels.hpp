@@ -98,6 +98,7 @@ struct AlacOptions {
     int32_t laneDecoder = 0;   // "decoder_lane" ALAC_HIP_DECODER=lane first-generation decoder
     int32_t decFused = -1;     // "dec_fused"    ALAC_HIP_DEC_FUSED   decode: entropy lanes || predictor waves in one launch
     int32_t decWide = 1;       // "dec_wide"     ALAC_HIP_DEC_WIDE    decode, separate launches: one lane per chain, sorted by taps
+    int32_t decPair = 1;       // "dec_pair"     ALAC_HIP_DEC_PAIR    decode, separate launches, 16-bit stereo: the predictor lanes of a packet un-mix and write the PCM
     int32_t decPubMask = 31;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols
     int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
     int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
@@ -186,7 +187,7 @@ struct DecodeArgs {
     DecRec *recs;       // [maxElems][numPackets]
     const uint32_t *gate = nullptr;  // lane decoder as a fallback: its kernels do nothing unless *gate != 0
     HandoffCtl ho;
-    int32_t optFused = -1, optWide = 1;  // AlacOptions::decFused / decWide (host-side launch choices)
+    int32_t optFused = -1, optWide = 1, optPair = 1;  // AlacOptions::decFused / decWide / decPair (host-side launch choices)
     uint32_t optPubMask = 31;            // AlacOptions::decPubMask
     int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
     uint8_t *pcmOut;
