@@ -116,7 +116,37 @@ struct DecV1Args {
     uint32_t outChannels;    // interleaved channels of the output frame (= element channels for mono / stereo)
     uint32_t outFirst;       // output channel of the element's first channel
     uint32_t *mismatch;      // null, or: k_dec_header counts the packets it gives status -4 (another element sequence) here
+    uint32_t lists;          // separate launches: k_dec_header sorts the packets / chains into work lists (dec_lists below)
+    uint32_t pairs;          // ... and lists the packets whose two chains unpc_pair_body takes (option dec_pair, one-lane predictor)
 };
+
+// Work lists of the separate-launch regime, built by k_dec_header (one lane per packet) in the progress words, which that
+// regime does not use:  [0, 2n) chains the one-lane predictor takes, 4-tap chains from the front, 8-tap chains from the back
+// | 16 counters: c4, c8, pairs A, pairs B, raw, rest | [n] pairs (class A from the front, B from the back) | [n] packets with
+// an uncompressed element (k_dec_raw) | [n] packets k_dec_unmix has to write (everything that is neither a pair nor an
+// uncompressed 16-bit stereo element, whose kernels write the PCM themselves: DecRec::pad2).
+constexpr uint32_t kDecCounters = 16;
+struct DecLists {
+    uint32_t *chains, *cnt, *pairs, *raw, *rest;
+};
+__device__ __host__ inline DecLists dec_lists(const DecV1Args &V)
+{
+    const uint64_t n = V.d.numPackets;
+    DecLists L;
+    L.chains = V.prog;
+    L.cnt = V.prog + 2 * n;
+    L.pairs = L.cnt + kDecCounters;
+    L.raw = L.pairs + n;
+    L.rest = L.raw + n;
+    return L;
+}
+// Pair mode (16-bit stereo into a stereo frame, the shape of the benchmark and of most files): a packet whose two chains
+// both take the fast predictor path is listed as a PAIR — class A (4 + 4 taps), class B (anything with an 8-tap chain) —
+// and its chains sit in adjacent lanes of unpc_pair_body, which un-mixes and writes the PCM itself.
+__device__ __host__ inline bool dec_stereo16(const DecV1Args &V)
+{
+    return V.d.bitDepth == 16 && V.d.numChannels == 2 && V.outChannels == 2 && V.elemBit == nullptr;
+}
 
 // lane states of the entropy kernel
 enum : uint32_t { kStIdle = 0, kStGolomb = 1, kStRaw = 2 };
@@ -138,6 +168,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     uint32_t numSamples = A.frameSize, ech = 0, shb = 0, chanBits = 0, esc = 0;
     int32_t status = (live && V.round > 0) ? A.statusOut[p] : 0;  // a packet that failed in an earlier round stays failed
     uint32_t pbU = A.pb, pbV = A.pb;
+    bool okc[2] = {false, false}, widec[2] = {false, false};  // chain c passes unpc_fast_ok's header part / has 8 taps
     DecRec R;
     R.numSamples = 0;
     R.escape = 0;
@@ -193,6 +224,8 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                         b = read_bits(base, nbytes, hpos, 8);
                         rec->c[c].pbFactor = (uint16_t)(b >> 5);
                         rec->c[c].num = (uint16_t)(b & 0x1f);
+                        okc[c] = rec->c[c].mode == 0 && rec->c[c].denShift == kDenShift && ((b & 0x1f) == 4 || (b & 0x1f) == 8);
+                        widec[c] = (b & 0x1f) == 8;
                         if (c == 0) pbU = (A.pb * (b >> 5)) / 4;  // :825
                         else pbV = (A.pb * (b >> 5)) / 4;        // :841
                         for (uint32_t i = 0; i < (b & 0x1f); i++)
@@ -258,7 +291,6 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         rec->shiftPos = R.shiftPos;
         rec->status = status;
         rec->pad = (uint32_t)hpos;  // first payload bit (entropy coded or raw), from the packet start
-        rec->pad2 = 0;              // set by k_dec_classify where the predictor lanes write the packet's PCM themselves
         A.statusOut[p] = status;
         if (V.mismatch && status == -4) atomicAdd(V.mismatch, 1u);  // gates the lane decoder behind this pipeline
         if (V.round == 0 || haveElement || status != 0) A.numSamplesOut[p] = status == 0 ? R.numSamples : 0;
@@ -266,10 +298,39 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         if (V.elemBit && status == 0 && haveElement && R.escape)
             V.elemBit[p] = (uint32_t)(hpos + (uint64_t)R.numSamples * R.elementChannels * A.bitDepth);
     }
+    // who writes this packet's PCM: the predictor lanes of a pair or k_dec_raw (pad2 = 1), or k_dec_unmix
+    const bool good = live && status == 0;
+    const bool stereo16 = dec_stereo16(V);
+    const bool fastShape = (A.frameSize & 7) == 0 && R.numSamples >= 16 && haveElement && !R.escape;  // unpc_fast_ok
+    const bool ok0 = good && fastShape && okc[0], ok1 = good && fastShape && R.elementChannels == 2 && okc[1];
+    const bool pair = stereo16 && V.lists && V.pairs && ok0 && ok1;
+    const bool rawP = good && haveElement && R.escape != 0;
+    const bool rawDirect = rawP && stereo16 && R.elementChannels == 2;
+    if (live) rec->pad2 = (pair || rawDirect) ? 1u : 0u;
+    if (V.lists) {
+        const DecLists L = dec_lists(V);
+        const uint64_t below = (1ull << lane) - 1;
+        auto push = [&](bool mine, uint32_t counter, uint32_t *list, uint32_t value, bool fromBack, uint32_t size) {
+            const uint64_t m = __ballot(mine);
+            uint32_t b = 0;
+            if (lane == 0 && m) b = atomicAdd(L.cnt + counter, (uint32_t)__popcll(m));
+            b = (uint32_t)__shfl((int)b, 0) + (uint32_t)__popcll(m & below);
+            if (mine) list[fromBack ? size - 1 - b : b] = value;
+        };
+        const uint32_t total = A.numPackets * A.numChannels;
+        const bool wide0 = widec[0], wide1 = widec[1];
+        push(ok0 && !pair && !wide0, 0, L.chains, p * A.numChannels, false, total);
+        push(ok0 && !pair && wide0, 1, L.chains, p * A.numChannels, true, total);
+        push(ok1 && !pair && !wide1, 0, L.chains, p * A.numChannels + 1, false, total);
+        push(ok1 && !pair && wide1, 1, L.chains, p * A.numChannels + 1, true, total);
+        push(pair && !wide0 && !wide1, 2, L.pairs, p, false, A.numPackets);
+        push(pair && (wide0 || wide1), 3, L.pairs, p, true, A.numPackets);
+        push(rawP, 4, L.raw, p, false, A.numPackets);
+        push(good && !pair && !rawDirect, 5, L.rest, p, false, A.numPackets);
+    }
     (void)pbU;
     (void)pbV;
     (void)chanBits;
-    (void)lane;
 }
 
 // ---- k_dec_raw: uncompressed (escape) elements are fixed-width fields, i.e. not serial at all: one thread per
@@ -285,6 +346,10 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
     const uint32_t *words = V.words + (off >> 2);
     const uint64_t lastWord = V.capWords - 2 - (off >> 2);  // k_dec_header has checked the payload; never index past the stage
     int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
+    // pad2 (k_dec_header): a 16-bit stereo element into a stereo frame — the fields ARE the PCM (codec/ALACDecoder.cu:856-874),
+    // written here as one word per frame instead of going through the plane and k_dec_unmix
+    const bool direct = rec->pad2 != 0;
+    uint32_t *pcm = (uint32_t *)(A.pcmOut + (uint64_t)p * A.frameSize * 4);
     // four sample-frames per round, every load of the round issued before its first store: the loop is bound by the
     // chain of dependent round trips per wave, not by bytes (an iteration per frame took 1.24 ms for the 15 600 escape
     // packets of the 125 000-packet benchmark)
@@ -306,14 +371,17 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t j = j0 + u * step;
+            uint32_t f[2] = {0, 0};
 #pragma unroll
             for (uint32_t c = 0; c < 2; c++) {
                 if (j < n && c < ech) {
                     const uint64_t two = ((uint64_t)hi[u][c] << 32) | lo[u][c];
                     const uint32_t v = (uint32_t)((two << shs[u][c]) >> 32) >> (32 - w);
-                    (rowU + c * A.frameSize)[j] = (int32_t)(v << (32 - w)) >> (32 - w);
+                    f[c] = v;
+                    if (!direct) (rowU + c * A.frameSize)[j] = (int32_t)(v << (32 - w)) >> (32 - w);
                 }
             }
+            if (direct && j < n) pcm[j] = f[0] | (f[1] << 16);
         }
     }
 }
@@ -324,9 +392,12 @@ __device__ __host__ inline uint32_t blocks_per_packet(uint32_t frameSize) { retu
 // A workgroup walks packets blockIdx.x, blockIdx.x + gridDim.x, ...: most packets are not escapes and a workgroup per
 // packet (times the blocks of a frame) spent the launch on workgroups that read one record and left — 1.23 ms for
 // 500 000 workgroups at 125 000 packets, 15 600 of them with work.
+// (round 3: the packets come from k_dec_header's list of uncompressed elements, so nobody reads records to find them)
 __global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
 {
-    for (uint32_t p = blockIdx.x; p < V.d.numPackets; p += gridDim.x) raw_body(V, p, threadIdx.x, blockDim.x);
+    const DecLists L = dec_lists(V);
+    const uint32_t count = L.cnt[4];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) raw_body(V, L.raw[i], threadIdx.x, blockDim.x);
 }
 
 // per-lane state of the entropy kernel
@@ -676,10 +747,14 @@ __global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
 }
 
 // the same with deferred residual stores (what the separate launches of a large batch use; ALAC_HIP_DEC_WIDE=0: the above)
-__global__ __launch_bounds__(64) void k_dec_entropy_wide(DecV1Args V)
+// Four waves to a workgroup: a CU then takes the entropy waves four at a time, one per SIMD.  As single-wave workgroups
+// (about 7.6 per CU at 125 000 packets) some SIMD of a CU ended up with three of them, and the launch is as slow as that SIMD.
+constexpr int kEntWavesPerWg = 4;
+__global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_entropy_wide(DecV1Args V, uint32_t nEnt)
 {
-    __shared__ uint32_t ring[64 * kWinStride];
-    entropy_body<false, true>(V, ring, blockIdx.x);
+    __shared__ uint32_t ring[kEntWavesPerWg][64 * kWinStride];
+    const uint32_t slot = threadIdx.x >> 6, b = blockIdx.x * (uint32_t)kEntWavesPerWg + slot;
+    if (b < nEnt) entropy_body<false, true>(V, ring[slot], b);
 }
 
 // ---- unpc_block (codec/dp_dec.c:55-381), in place over the chain's row ----
@@ -841,71 +916,9 @@ __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_b
 // Where every kernel fills the machine by itself the cost of the predictor is wave-instructions per chain step, and
 // the two-lane mapping above spends 58 per 32 chains.  Here a lane holds all T taps of its chain (T = 4 or 8 = the
 // chain's own tap count, so there are no dead taps, no cross-lane exchange and the weights are compile-time constants)
-// and a wave walks 64 chains.  k_dec_classify sorts the chains the fast path accepts by tap count into ONE list filled
-// from both ends (4-tap chains from the front, 8-tap chains from the back; it lives in the progress words of the fused
-// launch, which this regime does not use; the two counters sit behind them).
-// Pair mode (16-bit stereo into a stereo frame, the shape of the benchmark and of most files): a packet whose two chains
-// both take the fast path is listed as a PAIR instead — class A (4 + 4 taps) from the front of the pair list, class B
-// (anything with an 8-tap chain) from its back — and its chains sit in adjacent lanes of unpc_pair_body, which un-mixes
-// and writes the PCM itself; the record's pad2 tells k_dec_unmix to leave that packet alone.
-// prog layout here: [0, 2n) chain list | [2n, 2n + 16) counters c4, c8, pA, pB | [2n + 16, 3n + 16) pair list
-constexpr uint32_t kDecCounters = 16;
-__device__ __host__ inline bool dec_pair_mode(const DecV1Args &V)
-{
-    return V.d.bitDepth == 16 && V.d.numChannels == 2 && V.outChannels == 2 && V.elemBit == nullptr && V.d.optPair != 0;
-}
-
-__global__ __launch_bounds__(256) void k_dec_classify(DecV1Args V)
-{
-    const DecodeArgs &A = V.d;
-    const uint32_t total = A.numPackets * A.numChannels;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool pairMode = dec_pair_mode(V);
-    bool ok = false, wide = false;
-    uint32_t p = 0, ch = 0;
-    if (gid < total) {
-        p = gid / A.numChannels, ch = gid % A.numChannels;
-        const DecRec *rec = A.recs + p;
-        ok = unpc_fast_ok(A, rec, ch);
-        wide = ok && rec->c[ch].num == 8;
-    }
-    uint32_t *list = V.prog, *cnt = V.prog + 2 * (uint64_t)A.numPackets;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t below = (1ull << lane) - 1;
-    bool pairA = false, pairB = false;
-    if (pairMode) {
-        // the two chains of a packet are the lanes 2k, 2k + 1 of this wave (gid = 2 p + ch, 256 threads per workgroup)
-        const bool okO = __shfl_xor((int)ok, 1) != 0, wideO = __shfl_xor((int)wide, 1) != 0;
-        const bool both = ok && okO && A.recs[p].elementChannels == 2;
-        if (both) {
-            pairA = ch == 0 && !wide && !wideO;
-            pairB = ch == 0 && (wide || wideO);
-            ok = wide = false;  // not in the chain lists
-            if (ch == 0) A.recs[p].pad2 = 1;
-        }
-        uint32_t *pairs = cnt + kDecCounters;
-        const uint64_t mA = __ballot(pairA), mB = __ballot(pairB);
-        uint32_t bA = 0, bB = 0;
-        if (lane == 0) {
-            if (mA) bA = atomicAdd(cnt + 2, (uint32_t)__popcll(mA));
-            if (mB) bB = atomicAdd(cnt + 3, (uint32_t)__popcll(mB));
-        }
-        bA = (uint32_t)__shfl((int)bA, 0);
-        bB = (uint32_t)__shfl((int)bB, 0);
-        if (pairA) pairs[bA + (uint32_t)__popcll(mA & below)] = p;
-        if (pairB) pairs[A.numPackets - 1 - (bB + (uint32_t)__popcll(mB & below))] = p;
-    }
-    const uint64_t m4 = __ballot(ok && !wide), m8 = __ballot(wide);
-    uint32_t b4 = 0, b8 = 0;
-    if (lane == 0) {
-        if (m4) b4 = atomicAdd(cnt, (uint32_t)__popcll(m4));
-        if (m8) b8 = atomicAdd(cnt + 1, (uint32_t)__popcll(m8));
-    }
-    b4 = (uint32_t)__shfl((int)b4, 0);
-    b8 = (uint32_t)__shfl((int)b8, 0);
-    if (ok && !wide) list[b4 + (uint32_t)__popcll(m4 & below)] = gid;
-    if (wide) list[total - 1 - (b8 + (uint32_t)__popcll(m8 & below))] = gid;
-}
+// and a wave walks 64 chains.  k_dec_header has sorted the chains the fast path accepts by tap count into ONE list filled
+// from both ends (dec_lists), and the packets whose two chains both qualify into the pair list.
+constexpr uint64_t kDecFusedChains = 53248;  // up to here (26 624 stereo packets) one fused launch, above it separate launches
 
 // one unpc step of a lane that holds all T taps: returns out[j]; updates a[], the window w[] and tp
 template <int T>
@@ -949,9 +962,10 @@ __device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, uint32_t bloc
     const DecodeArgs &A = V.d;
     const uint32_t total = A.numPackets * A.numChannels;
     if (block * 64u >= count) return;
-    const uint32_t idx = block * 64u + threadIdx.x;
+    const uint32_t idx = block * 64u + (threadIdx.x & 63);
     const bool active = idx < count;
-    const uint32_t chain = active ? (T == 8 ? V.prog[total - 1 - idx] : V.prog[idx]) : 0;
+    const uint32_t *chains = dec_lists(V).chains;
+    const uint32_t chain = active ? (T == 8 ? chains[total - 1 - idx] : chains[idx]) : 0;
     const uint32_t p = chain / A.numChannels, ch = chain % A.numChannels;
     const DecRec *rec = A.recs + p;
     const uint32_t n = active ? rec->numSamples : 0;
@@ -1084,10 +1098,10 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t bloc
     if (block * 32u >= count) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t idx = block * 32u + lane / 2, ch = lane & 1;
-    const bool active = idx < count;
-    const uint32_t *pairs = V.prog + 2 * (uint64_t)A.numPackets + kDecCounters;
-    const uint32_t p = active ? (T == 8 ? pairs[A.numPackets - 1 - idx] : pairs[idx]) : 0;
+    const uint32_t *pairs = dec_lists(V).pairs;
+    const uint32_t p = idx < count ? (T == 8 ? pairs[A.numPackets - 1 - idx] : pairs[idx]) : 0;
     const DecRec *rec = A.recs + p;
+    const bool active = idx < count && rec->status == 0;  // a packet the entropy lane gave up on keeps its PCM untouched
     const uint32_t n = active ? rec->numSamples : 0;
     const uint32_t chanbits = A.bitDepth - (active ? rec->bytesShifted : 0) * 8 + 1;
     const bool is4 = T == 4 || !active || rec->c[ch].num == 4;
@@ -1210,12 +1224,13 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t bloc
 // As two launches, one after the other, each ran at about two waves per SIMD (2 266 and 1 640 waves at 125 000 stereo
 // packets) and was as slow as its own serial chain: 1.65 + 1.29 ms.
 // (pair mode: class-B pairs, 8-tap chains, class-A pairs, 4-tap chains)
-__global__ __launch_bounds__(64) void k_dec_unpc_wide(DecV1Args V)
+// Four waves to a workgroup (one per SIMD of its CU), consecutive roles: see k_dec_entropy_wide.
+__global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_unpc_wide(DecV1Args V)
 {
-    const uint32_t *cnt = V.prog + 2 * (uint64_t)V.d.numPackets;
+    const uint32_t *cnt = dec_lists(V).cnt;
     const uint32_t c4 = cnt[0], c8 = cnt[1], pA = cnt[2], pB = cnt[3];
     const uint32_t nbB = (pB + 31u) / 32u, nb8 = (c8 + 63u) / 64u, nbA = (pA + 31u) / 32u;
-    uint32_t b = blockIdx.x;
+    uint32_t b = blockIdx.x * (uint32_t)kEntWavesPerWg + (threadIdx.x >> 6);
     if (b < nbB) return unpc_pair_body<8>(V, b, pB);
     b -= nbB;
     if (b < nb8) return unpc_wide_body<8>(V, b, c8);
@@ -1286,11 +1301,9 @@ __device__ __forceinline__ void put_sample(uint8_t *q, int32_t x)
 }
 
 template <int DEPTH, int CH>
-__global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
+__device__ __forceinline__ void unmix_part(const DecV1Args &V, uint32_t p, uint32_t part, uint32_t bx)
 {
     const DecodeArgs &A = V.d;
-    const uint32_t bx = blocks_per_packet(A.frameSize);
-    const uint32_t p = blockIdx.x / bx;
     const DecRec *rec = A.recs + p;
     if (rec->status != 0 || rec->pad2 != 0) return;  // pad2: unpc_pair_body wrote this packet's PCM
     // element rounds: a packet that ended before this element leaves these channels zero (codec/ALACDecoder.cu:971-998)
@@ -1310,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
             typedef int32_t I4 __attribute__((ext_vector_type(4), aligned(4)));
             typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
             const uint32_t n4 = n & ~3u;
-            for (uint32_t j = ((blockIdx.x % bx) * blockDim.x + threadIdx.x) * 4; j < n4; j += bx * blockDim.x * 4) {
+            for (uint32_t j = (part * blockDim.x + threadIdx.x) * 4; j < n4; j += bx * blockDim.x * 4) {
                 const I4 zz = {0, 0, 0, 0};
                 const I4 uu = absent ? zz : *(const I4 *)(u + j), vv = absent ? zz : *(const I4 *)(v + j);
                 U4 o;
@@ -1329,7 +1342,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
                 *(U4 *)(out + (uint64_t)j * 4) = o;
             }
             // the last n mod 4 frames of a short packet
-            for (uint32_t j = n4 + (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
+            for (uint32_t j = n4 + part * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
                 const int32_t uu = absent ? 0 : u[j], vv = absent ? 0 : v[j];
                 int32_t l, r;
                 if (mixRes != 0) {
@@ -1344,7 +1357,7 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
             return;
         }
     }
-    for (uint32_t j = (blockIdx.x % bx) * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
+    for (uint32_t j = part * blockDim.x + threadIdx.x; j < n; j += bx * blockDim.x) {
         int32_t l, r = 0;
         if constexpr (CH == 2) {
             const int32_t uu = absent ? 0 : u[j], vv = absent ? 0 : v[j];
@@ -1375,10 +1388,27 @@ __global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
     }
 }
 
+// Fused launch: workgroup = (packet, part of the frame).  Separate launches: the workgroups walk k_dec_header's list of the
+// packets nobody else writes (with pairs and direct uncompressed elements that is none of the benchmark's packets; launching
+// a workgroup per packet just to read a record and leave cost 0.5 ms at 125 000 packets).
+template <int DEPTH, int CH>
+__global__ __launch_bounds__(256) void k_dec_unmix(DecV1Args V)
+{
+    const uint32_t bx = blocks_per_packet(V.d.frameSize);
+    if (!V.lists) {
+        unmix_part<DEPTH, CH>(V, blockIdx.x / bx, blockIdx.x % bx, bx);
+        return;
+    }
+    const DecLists L = dec_lists(V);
+    const uint64_t work = (uint64_t)L.cnt[5] * bx;
+    for (uint64_t i = blockIdx.x; i < work; i += gridDim.x) unmix_part<DEPTH, CH>(V, L.rest[i / bx], (uint32_t)(i % bx), bx);
+}
+
 template <int DEPTH>
 static void launch_unmix_v1(const DecV1Args &V, hipStream_t st)
 {
-    dim3 grid(blocks_per_packet(V.d.frameSize) * V.d.numPackets);
+    const uint64_t all = (uint64_t)blocks_per_packet(V.d.frameSize) * V.d.numPackets;
+    dim3 grid((uint32_t)(V.lists && all > 8192 ? 8192 : all));
     if (V.d.numChannels == 2)
         hipLaunchKernelGGL((k_dec_unmix<DEPTH, 2>), grid, dim3(256), 0, st, V);
     else
@@ -1392,12 +1422,13 @@ struct DecSide {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSide *side = nullptr, bool stageFirst = false)
+static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecSide *side = nullptr, bool stageFirst = false)
 {
+    DecV1Args V = V0;
     const DecodeArgs &da = V.d;
     const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
     const int forced0 = V.d.optFused;
-    const bool fused0 = forced0 >= 0 ? forced0 != 0 : (uint64_t)da.numPackets * da.numChannels <= 65536;
+    const bool fused0 = forced0 >= 0 ? forced0 != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
     const bool useSide = side && side->stream && fused0;
     hipStream_t sc = useSide ? side->stream : st;  // the clears
     if (useSide) {
@@ -1413,6 +1444,9 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSi
     if (!zerosWritten) (void)hipMemsetAsync(V.plane, 0, planeBytes, sc);
     if (useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, sc);
     if (V.mismatch) (void)hipMemsetAsync(V.mismatch, 0, 4, st);
+    V.lists = fused0 ? 0u : 1u;
+    V.pairs = (!fused0 && V.d.optWide != 0 && V.d.optPair != 0) ? 1u : 0u;
+    if (V.lists) (void)hipMemsetAsync(dec_lists(V).cnt, 0, kDecCounters * 4, st);
     if (stageFirst)
         hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
                            V.capWords);
@@ -1425,10 +1459,11 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSi
     const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
     // One launch (entropy lanes followed by the predictor waves, producer/consumer through HBM) where the chains are few
     // enough that a stage is as slow as its longest serial chain; separate launches where every kernel fills the machine by
-    // itself (no polling, no release fence per publish).  Measured at 125 000 packets: 17.6 ms fused, 12.5 ms separate;
-    // at 10 000: 2.06 fused, 2.50 separate.  ALAC_HIP_DEC_FUSED=0/1 forces.
+    // itself (no polling, no release fence per publish).  Measured, fused / separate, 16-bit stereo packets (round 3,
+    // profiles/r03/regime_sweep.log): 10 000 1.95 / 2.95 ms, 18 000 2.42 / 3.26, 26 000 2.86 / 3.35, 30 000 3.80 / 3.43,
+    // 125 000 17.6 (round 1) / 6.93.  Option dec_fused (ALAC_HIP_DEC_FUSED) = 0 / 1 forces.
     const int forced = V.d.optFused;
-    const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= 65536;
+    const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
     if (fused) {
         if (!useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
         // predictor waves per entropy wave: 64 packets x channels / 32 chains, and enough of them for all of nUnpc
@@ -1438,23 +1473,20 @@ static hipError_t decode_v1_pass(const DecV1Args &V, hipStream_t st, const DecSi
         hipLaunchKernelGGL(k_dec_fused, dim3((uint32_t)((workers + kDecWavesPerWg - 1) / kDecWavesPerWg)), dim3(64 * kDecWavesPerWg), 0, st, V,
                            nEnt, nUnpc, per);
     } else {
-        // a prime number of workgroups: escape packets that recur with a period (every 8th packet of the benchmark's signal
-        // classes) must not all land on the same few workgroups
-        hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4093u ? da.numPackets : 4093u), dim3(256), 0, st, V);
+        hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4096u ? da.numPackets : 4096u), dim3(256), 0, st, V);
         const bool wide = V.d.optWide != 0;
         // deferred residual stores, four 16-byte stores per round of sixteen consecutive residuals (round 2, 4-byte stores:
         // paid only up to two entropy waves per SIMD; with the wide stores, measured whole decode pass at 125 000 / 250 000 /
         // 500 000 packets: 9.31 -> 8.19, 19.4 -> 14.2, 38.1 -> 26.5 ms — the kernel was bound by the number of store
         // instructions whose 64 lanes hit 64 different cache lines, which a CU's address path takes one line at a time)
         if (wide)
-            hipLaunchKernelGGL(k_dec_entropy_wide, dim3(nEnt), dim3(64), 0, st, V);
+            hipLaunchKernelGGL(k_dec_entropy_wide, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
         else
             hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
         if (wide) {
             // chains sorted by tap count, one lane per chain (ALAC_HIP_DEC_WIDE=0: the two-lane kernel of the fused launch)
-            (void)hipMemsetAsync(V.prog + 2 * (uint64_t)da.numPackets, 0, kDecCounters * 4, st);
-            hipLaunchKernelGGL(k_dec_classify, dim3((uint32_t)((lanes + 255) / 256)), dim3(256), 0, st, V);
-            hipLaunchKernelGGL(k_dec_unpc_wide, dim3((uint32_t)((lanes + 63) / 64) + 4), dim3(64), 0, st, V);
+            hipLaunchKernelGGL(k_dec_unpc_wide, dim3(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg),
+                               dim3(64 * kEntWavesPerWg), 0, st, V);
         } else {
             hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
         }
@@ -1481,6 +1513,7 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
     V.pubMask = da.optPubMask;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
     V.elemBit = nullptr;
     V.mismatch = nullptr;
+    V.lists = V.pairs = 0;  // decode_v1_pass decides
     V.round = 0;
     V.outChannels = da.numChannels;
     V.outFirst = 0;
