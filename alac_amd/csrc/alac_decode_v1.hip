@@ -67,7 +67,8 @@ __device__ __forceinline__ uint32_t bw_pos(const BitWin &b) { return (b.idx - 2u
 
 __device__ __forceinline__ uint32_t bw_peek(const BitWin &b)
 {
-    return b.o ? ((b.w0 << b.o) | (b.w1 >> (32u - b.o))) : b.w0;
+    // one 64-bit shift (v_lshlrev_b64) instead of the shift-by-zero-safe funnel of two 32-bit words (four instructions)
+    return (uint32_t)(((((uint64_t)b.w0 << 32) | b.w1) << b.o) >> 32);
 }
 
 __device__ __forceinline__ void bw_skip(BitWin &b, uint32_t n)  // n <= 32
@@ -487,6 +488,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         dpos[k] = 0;
         dval[k] = 0;
     }
+    uint32_t lim = 0;   // see the round loop
     bool had = false;   // this lane decoded something in the round the pairs come from
     bool full = false;  // ... and decoded its last symbol (so all of them)
     // A lane that stops decoding inside a round stays stopped (and repeats its last pair), and positions only grow: when the
@@ -529,32 +531,34 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
             pendBase = E.F;
         }
         asm volatile("" ::: "memory");
+        // a lane decodes while it is active and has >= 128 staged bits ahead of its window: F only changes between rounds,
+        // so that is "idx <= lim" with one limit per round (0 = never: idx starts at 2); whoever clears `active` clears it
+        lim = E.active ? E.F - 4u : 0u;
 #pragma unroll
         for (int it = 0; it < kDecRound; it++) {
             if constexpr (WIDE) {
                 dpos[it] = lastPos;
                 dval[it] = lastVal;
             }
-            // still decoding, and >= 160 staged bits ahead of the window (one condition, one branch)
-            if ((uint32_t)(E.active != 0) & (uint32_t)(E.F - bw.idx >= 4)) {
+            if (bw.idx <= lim) {
                 // ---- one residual: dyn_get_32bit (ag_dec.c:220-270), straight-line for the common case ----
                 const uint32_t k = min(22u - (uint32_t)__builtin_clz(E.mb + (3u << kQBShift)), A.kb);  // lg3a(mb >> 9)
-                const uint32_t m = (1u << k) - 1;
                 const uint32_t stream = bw_peek(bw);
                 const uint32_t pre = (uint32_t)__builtin_clz(~stream | 1u);  // leading ones, at most 31
-                const uint32_t v = (stream << (pre + 1)) >> (32 - k);        // only meaningful below the escape
+                // the k bits behind the prefix and its closing zero (only meaningful below the escape: pre <= 8, k <= 16)
+                const uint32_t v = __builtin_amdgcn_ubfe(stream, 31u - k - pre, k);
                 const uint32_t big = v >= 2 ? 1u : 0u;
-                uint32_t n = k != 1 ? pre * m + (big ? v - 1 : 0u) : pre;
-                uint32_t used = pre + 1 + (k != 1 ? k - 1 + big : 0u);
+                // ag_dec.c:248-262 without its k != 1 case: with k = 1, m = 1 and v < 2, so the general form gives the
+                // same value (pre) and the same length (pre + 1)
+                uint32_t n = (pre << k) - pre + (big ? v - 1 : 0u);
+                uint32_t used = pre + k + big;
                 // (ag_dec.c:302 stops a channel whose next residual would start at or past the packet's end; such a
                 // channel also fails the end check below — the position only grows — so the status is the same and
                 // the per-residual test is not repeated here)
-                if (__any(pre >= kMaxPrefix)) {
-                    if (pre >= kMaxPrefix) {
-                        bw_skip(bw, kMaxPrefix);
-                        n = bw_get(bw, chanBits);
-                        used = 0;
-                    }
+                if (pre >= kMaxPrefix) {
+                    bw_skip(bw, kMaxPrefix);
+                    n = bw_get(bw, chanBits);
+                    used = 0;
                 }
                 bw_skip(bw, used);
                 const uint32_t nd = n + E.zmode;
@@ -575,8 +579,10 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                 mb = n > kMeanClamp ? kMeanClamp : mb;
                 E.mb = mb;
                 E.zmode = 0;
-                const bool zrun = ((mb << 2) < (1u << kQBShift)) && (E.c < numSamples) && E.active;
-                if (__any(zrun || E.c >= numSamples)) {
+                // (a lane in here is active: lim is 0 otherwise)
+                const bool low = (mb << 2) < (1u << kQBShift), atEnd = E.c >= numSamples;
+                if (__any(low | atEnd)) {
+                    const bool zrun = low && !atEnd;
                     int32_t *zfAt = nullptr;  // ZFILL: where this lane's run of zfCnt zeros starts
                     uint32_t zfCnt = 0;
                     if (zrun) {
@@ -604,6 +610,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                         if (!((uint64_t)E.c + nz <= (uint64_t)numSamples)) {  // :341
                             E.status = -50;
                             E.active = 0;
+                            lim = 0;
                         } else if constexpr (ZFILL) {
                             zfAt = rowBase + rowOff + E.c;
                             zfCnt = nz;
@@ -642,6 +649,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                         if ((uint64_t)(bw_pos(bw) - bit0 + 7) / 8 > nbytes) {
                             E.status = -50;
                             E.active = 0;
+                            lim = 0;
                         } else if (E.chan + 1 < ech) {
                             E.chan++;
                             E.c = 0;
@@ -653,6 +661,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
                         } else {
                             E.endPos = bw_pos(bw) - bit0;
                             E.active = 0;
+                            lim = 0;
                         }
                     }
                 }
