@@ -65,6 +65,7 @@ AlacOptions alac_options_from_env()
     if (const char *e = getenv("ALAC_HIP_DEC_FUSED")) o.decFused = *e ? (e[0] == '0' ? 0 : 1) : -1;
     o.decWide = env_int("ALAC_HIP_DEC_WIDE", o.decWide) != 0;
     o.decPair = env_int("ALAC_HIP_DEC_PAIR", o.decPair) != 0;
+    o.decLocal = env_int("ALAC_HIP_DEC_LOCAL", o.decLocal) != 0;
     o.decPubMask = env_int("ALAC_HIP_DEC_PUBMASK", o.decPubMask);
     o.stageTaps = env_int("ALAC_HIP_STAGE_TAPS", o.stageTaps) != 0;
     o.loseHandoff = env_int("ALAC_HIP_DEBUG_LOSE_HANDOFF", o.loseHandoff) == 1;
@@ -89,7 +90,7 @@ int32_t *alac_option_slot(AlacOptions &o, const char *key)
         {"overlap_pos", &AlacOptions::overlapPos}, {"fused", &AlacOptions::fused},
         {"subbatch", &AlacOptions::subBatch},   {"encoder_lane", &AlacOptions::laneEncoder},
         {"decoder_lane", &AlacOptions::laneDecoder}, {"dec_fused", &AlacOptions::decFused},
-        {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask}, {"dec_pair", &AlacOptions::decPair},
+        {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask}, {"dec_pair", &AlacOptions::decPair}, {"dec_local", &AlacOptions::decLocal},
         {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
         {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
         {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"thru_wg4", &AlacOptions::thruWg4}, {"fast_mode", &AlacOptions::fastMode}, {"lds_pad", &AlacOptions::ldsPad},
@@ -955,6 +956,7 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.optFused = ctx->opt.decFused;
     da.optWide = ctx->opt.decWide;
     da.optPair = ctx->opt.decPair;
+    da.optLocal = ctx->opt.decLocal;
     da.optPubMask = (uint32_t)ctx->opt.decPubMask;
     hipError_t e;
     if (use_lane_decoder(ctx)) {

@@ -422,7 +422,7 @@ struct EntLane {
 // packets: 4.1 ms with the stores, 2.8 ms without them).  Here a round only RECORDS (position, value) per symbol; the
 // stores are issued at the start of the next round, right after the wait, and have a whole round to complete.  A symbol
 // that was not decoded repeats the lane's previous pair (same value to the same address: harmless).
-template <bool PB40, bool PUB, bool WIDE = false, bool ZFILL = WIDE>
+template <bool PB40, bool PUB, bool WIDE = false, bool ZFILL = WIDE, bool LOCAL = false>
 __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, uint32_t *ringRow, uint64_t wordBase,
                                                uint32_t cur0, uint32_t bit0, uint32_t limit, uint64_t nbytes,
                                                uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV,
@@ -463,15 +463,26 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         if constexpr (PUB) {
             // per-lane 4-byte stores cannot be written through one by one (16 x HBM write amplification, measured):
             // plain stores, and an agent-scope release (L2 write-back, ~10 us) at every publish instead
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t all = 0xffffffffu;
             const uint32_t u = (!E.active || E.chan > 0) ? all : E.c;
             const uint32_t v = !E.active ? all : (E.chan > 0 ? E.c : 0u);
-            if (prog && !A.ho.lose) {
-                __hip_atomic_store(prog, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(prog + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (LOCAL) {
+                // the followers are waves of THIS workgroup (k_dec_fused_wg): same CU, same L1 and L2 — the stores only
+                // have to have left the wave (workgroup-scope release: no cache write-back), and the progress words are LDS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (prog && !A.ho.lose) {
+                    __hip_atomic_store(prog, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(prog + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (prog && !A.ho.lose) {
+                    __hip_atomic_store(prog, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(prog + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     };
@@ -674,13 +685,15 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
     publish();  // everything is complete (or failed): nobody waits for this lane any more
 }
 
-template <bool PUB, bool WIDE = false, bool ZFILL = WIDE>
-__device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block)
+// PPW: packets per wave (lanes PPW .. 63 idle); progLds: LOCAL progress words of the workgroup, [PPW][2]
+template <bool PUB, bool WIDE = false, bool ZFILL = WIDE, int PPW = 64>
+__device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block, uint32_t *progLds = nullptr)
 {
+    constexpr bool LOCAL = PPW != 64;
     const DecodeArgs &A = V.d;
     const int lane = threadIdx.x & 63;
-    const uint32_t p = block * 64u + lane;
-    const bool live = p < A.numPackets;
+    const uint32_t p = block * (uint32_t)PPW + lane;
+    const bool live = lane < PPW && p < A.numPackets;
     const uint64_t off = live ? A.offsets[p] : 0;
     const uint64_t nbytes = live ? A.offsets[p + 1] - off : 0;
     DecRec *rec = A.recs + (live ? p : 0);
@@ -735,11 +748,11 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
     E.endPos = 0;
     E.row = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
 
-    uint32_t *prog = (PUB && live) ? V.prog + (uint64_t)p * 2 : nullptr;
+    uint32_t *prog = (PUB && live) ? (LOCAL ? progLds + lane * 2 : V.prog + (uint64_t)p * 2) : nullptr;
     if (__all(!coded || (pbU == 40 && pbV == 40)))
-        entropy_rounds<true, PUB, WIDE, ZFILL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<true, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
     else
-        entropy_rounds<false, PUB, WIDE, ZFILL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<false, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
 
     if (live && E.status != status0) {
         rec->status = E.status;
@@ -809,15 +822,26 @@ __device__ __forceinline__ void unpc_head16(const int32_t (&del)[16], int32_t (&
 
 // FOLLOW: fused launch — the wave's chains are all of one channel (q = channel * numPackets + packet), and rows are
 // only read once the entropy lane of their packet has published them.
-template <bool FOLLOW>
-__device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t block)
+// PPW != 64 (k_dec_fused_wg): `block` = workgroup * 3 + r, the r-th of the three predictor waves behind the workgroup's
+// entropy wave; its chains are slots r * 32 .. r * 32 + 31 of the workgroup's PPW first-channel chains followed by its PPW
+// second-channel chains, and the progress words are the workgroup's (LDS).
+template <bool FOLLOW, int PPW = 64>
+__device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t block, const uint32_t *progLds = nullptr)
 {
+    constexpr bool LOCAL = PPW != 64;
     const DecodeArgs &A = V.d;
     const int lane = threadIdx.x & 63;
     const uint64_t q = (uint64_t)block * 32u + lane / 2;
-    const bool inRange = q < (uint64_t)A.numPackets * A.numChannels;
-    uint32_t p, ch;
-    if (FOLLOW) {
+    bool inRange = q < (uint64_t)A.numPackets * A.numChannels;
+    uint32_t p, ch, slotLocal = 0;
+    if constexpr (LOCAL) {
+        const uint32_t wg = block / 3u, s = (block % 3u) * 32u + (uint32_t)lane / 2;
+        ch = s / (uint32_t)PPW;
+        slotLocal = s % (uint32_t)PPW;
+        p = wg * (uint32_t)PPW + slotLocal;
+        inRange = ch < A.numChannels && p < A.numPackets;
+        if (!inRange) p = ch = 0;
+    } else if (FOLLOW) {
         ch = inRange ? (uint32_t)(q / A.numPackets) : 0;
         p = inRange ? (uint32_t)(q % A.numPackets) : 0;
     } else {
@@ -830,7 +854,7 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
     if (!__any(active)) return;
     const uint32_t n = active ? rec->numSamples : 0;
     // rows < `rows` (capped at the lane's own length) must have been published before they are loaded
-    const uint32_t *progPtr = V.prog + (uint64_t)p * 2 + ch;
+    const uint32_t *progPtr = LOCAL ? progLds + slotLocal * 2 + ch : V.prog + (uint64_t)p * 2 + ch;
     uint32_t availMin = 0;
     auto need = [&](uint32_t rows) {
         if constexpr (FOLLOW) {
@@ -839,7 +863,10 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
             bool seen = false;
             uint32_t a = 0;
             for (uint32_t spins = 0; spins < A.ho.spinLimit; spins++) {
-                a = active ? __hip_atomic_load(progPtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                if constexpr (LOCAL)
+                    a = active ? __hip_atomic_load(progPtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xffffffffu;
+                else
+                    a = active ? __hip_atomic_load(progPtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
                 if (__all(a >= want)) {
                     availMin = wave_min_dec(a);
                     seen = true;
@@ -855,7 +882,10 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
                 if (A.ho.err && lane == 0) __hip_atomic_store(A.ho.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 availMin = 0xffffffffu;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if constexpr (LOCAL)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            else
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     };
     need(16);
@@ -1276,6 +1306,31 @@ __global__ __launch_bounds__(64 * kDecWavesPerWg, 1) void k_dec_fused(DecV1Args 
     }
 }
 
+// ---- fused launch, round 3 form: the followers of an entropy wave are waves of ITS workgroup.  A workgroup = the entropy
+// wave of kFusedPpw = 48 packets + the three predictor waves of their 96 chains (first-channel chains, then second-channel
+// chains, 32 to a wave), one wave per SIMD of one CU.  Producer and followers share that CU's L1 and L2, so a publish is a
+// workgroup-scope release (wait for the stores to leave the wave) and two LDS words per packet — in the form above it is an
+// agent-scope release, i.e. an L2 write-back of ~10 us, sixteen times per packet.  Workgroups >= nEnt: one wave per packet
+// for the uncompressed elements, as above.
+constexpr int kFusedPpw = 48;
+__global__ __launch_bounds__(256, 1) void k_dec_fused_wg(DecV1Args V, uint32_t nEnt)
+{
+    __shared__ uint32_t ringOne[64 * kWinStride];
+    __shared__ uint32_t progLds[kFusedPpw * 2];
+    const uint32_t slot = threadIdx.x >> 6;
+    if (blockIdx.x < nEnt) {
+        if (threadIdx.x < kFusedPpw * 2) progLds[threadIdx.x] = 0;
+        __syncthreads();
+        if (slot == 0)
+            entropy_body<true, false, false, kFusedPpw>(V, ringOne, blockIdx.x, progLds);
+        else
+            unpc_fast_body<true, kFusedPpw>(V, blockIdx.x * 3u + (slot - 1), progLds);
+    } else {
+        const uint32_t p = (blockIdx.x - nEnt) * 4u + slot;
+        if (p < V.d.numPackets) raw_body(V, p, threadIdx.x & 63, 64);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_dec_unpc(DecV1Args V)
 {
     const DecodeArgs &A = V.d;
@@ -1541,7 +1596,10 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     // 125 000 17.6 (round 1) / 6.93.  Option dec_fused (ALAC_HIP_DEC_FUSED) = 0 / 1 forces.
     const int forced = V.d.optFused;
     const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
-    if (fused) {
+    if (fused && V.d.optLocal != 0) {
+        const uint32_t nEntWg = (da.numPackets + kFusedPpw - 1) / kFusedPpw;
+        hipLaunchKernelGGL(k_dec_fused_wg, dim3(nEntWg + (da.numPackets + 3) / 4), dim3(256), 0, st, V, nEntWg);
+    } else if (fused) {
         if (!useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
         // predictor waves per entropy wave: 64 packets x channels / 32 chains, and enough of them for all of nUnpc
         uint32_t per = 2 * da.numChannels;
@@ -1587,7 +1645,10 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
     V.capWords = capWords;
     V.plane = plane;
     V.prog = prog;
-    V.pubMask = da.optPubMask;  // every 512 symbols: ~10 us of L2 write-back per publish, 16 publishes per packet
+    // publish every (mask + 1) rounds of 16 residuals: workgroup-local followers 8 (a publish only waits for the wave's own
+    // stores; measured at 10 000 packets, mask 31 / 15 / 7 / 3 / 1: 1.749 / 1.723 / 1.717 / 1.717 / 1.729 ms), followers anywhere
+    // on the chip 32 (every publish is an L2 write-back)
+    V.pubMask = da.optPubMask != 0xffffffffu ? da.optPubMask : (da.optLocal != 0 ? 7u : 31u);
     V.elemBit = nullptr;
     V.mismatch = nullptr;
     V.lists = V.pairs = 0;  // decode_v1_pass decides

@@ -99,7 +99,8 @@ struct AlacOptions {
     int32_t decFused = -1;     // "dec_fused"    ALAC_HIP_DEC_FUSED   decode: entropy lanes || predictor waves in one launch
     int32_t decWide = 1;       // "dec_wide"     ALAC_HIP_DEC_WIDE    decode, separate launches: one lane per chain, sorted by taps
     int32_t decPair = 1;       // "dec_pair"     ALAC_HIP_DEC_PAIR    decode, separate launches, 16-bit stereo: the predictor lanes of a packet un-mix and write the PCM
-    int32_t decPubMask = 31;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols
+    int32_t decLocal = 1;      // "dec_local"    ALAC_HIP_DEC_LOCAL   fused decode: the followers of an entropy wave are waves of its workgroup (LDS progress, no L2 write-back)
+    int32_t decPubMask = -1;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols (-1: 7 with dec_local, else 31)
     int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
     int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
     int32_t initState = 0;     // "init_state"   ALAC_HIP_INIT_STATE  1: k_init_state writes the workspace rows even where the kernels take
@@ -187,8 +188,8 @@ struct DecodeArgs {
     DecRec *recs;       // [maxElems][numPackets]
     const uint32_t *gate = nullptr;  // lane decoder as a fallback: its kernels do nothing unless *gate != 0
     HandoffCtl ho;
-    int32_t optFused = -1, optWide = 1, optPair = 1;  // AlacOptions::decFused / decWide / decPair (host-side launch choices)
-    uint32_t optPubMask = 31;            // AlacOptions::decPubMask
+    int32_t optFused = -1, optWide = 1, optPair = 1, optLocal = 1;  // AlacOptions::decFused / decWide / decPair (host-side launch choices)
+    uint32_t optPubMask = 0xffffffffu;   // AlacOptions::decPubMask (-1: 7 with workgroup-local followers, 31 otherwise)
     int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
     uint8_t *pcmOut;
     uint32_t *numSamplesOut;

@@ -72,7 +72,7 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  *   "fused" (0/1)          encode: predictor || entropy coder as one producer/consumer launch (latency regime)
  *   "idlefast", "wide81" (-1/0/1), "split_coder", "overlap_pos", "pubfence" (0/1), "subbatch" (0..8), "persist" (-1/0/1)
  *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels
- *   "dec_fused" (-1/0/1), "dec_wide" (0/1), "dec_pubmask"   decode launch shape
+ *   "dec_fused" (-1/0/1), "dec_wide" (0/1), "dec_pair" (0/1), "dec_local" (0/1), "dec_pubmask" (-1 = auto)   decode launch shape
  *   "stage_taps" (0/1)     alac_hip_pc_block: tap-parallel kernel for 5..30 taps
  *   "debug_lose_handoff" (0/1)  test switch: producers of the in-launch hand-offs never publish
  * Every setting produces the same bytes; only the kernels that run differ.  Unknown key -> kALAC_ParamError. */

@@ -27,6 +27,7 @@ VARIANTS = {
     "positions-not-overlapped": {"overlap_pos": 0},
     "unfused-two-lane-decode-predictor": {"dec_fused": 0, "dec_wide": 0},
     "unfused-decode-chains-not-paired": {"dec_fused": 0, "dec_pair": 0},
+    "fused-decode-followers-anywhere": {"dec_local": 0},
     "tiny-batch-coder-not-split": {"split_coder": 0},
     "chained-not-persistent": {"persist": 0},
 }
