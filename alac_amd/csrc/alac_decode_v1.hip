@@ -957,7 +957,7 @@ __global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_b
 // chain's own tap count, so there are no dead taps, no cross-lane exchange and the weights are compile-time constants)
 // and a wave walks 64 chains.  k_dec_header has sorted the chains the fast path accepts by tap count into ONE list filled
 // from both ends (dec_lists), and the packets whose two chains both qualify into the pair list.
-constexpr uint64_t kDecFusedChains = 53248;  // up to here (26 624 stereo packets) one fused launch, above it separate launches
+constexpr uint64_t kDecFusedChains = 65536;  // up to here (32 768 stereo packets) one fused launch, above it separate launches
 
 // one unpc step of a lane that holds all T taps: returns out[j]; updates a[], the window w[] and tp
 template <int T>
@@ -1591,9 +1591,9 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
     // One launch (entropy lanes followed by the predictor waves, producer/consumer through HBM) where the chains are few
     // enough that a stage is as slow as its longest serial chain; separate launches where every kernel fills the machine by
-    // itself (no polling, no release fence per publish).  Measured, fused / separate, 16-bit stereo packets (round 3,
-    // profiles/r03/regime_sweep.log): 10 000 1.95 / 2.95 ms, 18 000 2.42 / 3.26, 26 000 2.86 / 3.35, 30 000 3.80 / 3.43,
-    // 125 000 17.6 (round 1) / 6.93.  Option dec_fused (ALAC_HIP_DEC_FUSED) = 0 / 1 forces.
+    // itself (no polling, no release fence per publish).  Measured, fused / separate, 16-bit stereo packets (round 3, HEAD;
+    // profiles/r03/regime_sweep.log): 10 000 1.72 / 2.9 ms, 22 000 2.19 / 2.78, 26 000 2.58 / 2.86, 30 000 2.78 / 2.85,
+    // 34 000 2.84 / 2.88, 125 000 17.6 (round 1) / 5.3.  Option dec_fused (ALAC_HIP_DEC_FUSED) = 0 / 1 forces.
     const int forced = V.d.optFused;
     const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
     if (fused && V.d.optLocal != 0) {
