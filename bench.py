@@ -390,8 +390,9 @@ def decode_leg(torch, ctx, fmt, B, stream, offsets, d_pcm, reps):
             "round_trip_exact": bool(torch.equal(d_out, d_pcm)) and int(d_st.abs().sum()) == 0,
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tstep, "traffic_source": tnote,
-                         "kernel": "whole decode pass (k_dec_stage, k_dec_header, k_dec_fused or k_dec_entropy + k_dec_unpc_*, "
-                                   "k_dec_raw, k_dec_unmix)",
+                         "kernel": "whole decode pass (k_dec_stage, k_dec_header, then up to 65 536 chains k_dec_fused_wg [entropy wave + "
+                                   "its three predictor waves per workgroup], above that k_dec_raw, k_dec_entropy_wide, k_dec_unpc_wide "
+                                   "[pairs write the PCM]; k_dec_unpc, k_dec_unmix for what is left)",
                          "kernel_ms": round(ev_ms, 4), "algorithmic_bytes_per_launch": comp,
                          "note": "compulsory = packed stream in + PCM out; HIP events on the context's stream around the timed "
                                  "passes; bound by the serial adaptive-Golomb bit walk per packet, not by HBM"}}
