@@ -57,9 +57,8 @@ __global__ __launch_bounds__(256) void k_dec_stage(const uint8_t *stream, const 
 struct BitWin {
     uint32_t w0, w1;     // words idx-2 and idx-1 of the lane's word stream
     uint32_t o;          // bits of w0 already consumed (0..31)
-    uint32_t idx;        // index of the look-ahead word (relative to the packet's first staged word)
-    uint32_t nw;         // look-ahead word, ring[(idx - org) & 31]
-    uint32_t org;        // word index that lives in ring slot 0
+    uint32_t idx;        // index of the look-ahead word, relative to the word that was staged into ring slot 0
+    uint32_t nw;         // look-ahead word, ring[idx & 31]
     const uint32_t *ring;
 };
 
@@ -79,7 +78,7 @@ __device__ __forceinline__ void bw_skip(BitWin &b, uint32_t n)  // n <= 32
     b.w0 = carry ? b.w1 : b.w0;
     b.w1 = carry ? b.nw : b.w1;
     b.idx += carry ? 1u : 0u;
-    b.nw = b.ring[(b.idx - b.org) & 31u];
+    b.nw = b.ring[b.idx & 31u];
 }
 
 __device__ __forceinline__ uint32_t bw_get(BitWin &b, uint32_t n)  // 1 <= n <= 32
@@ -448,7 +447,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
         }
     };
     auto write16 = [&](uint32_t rel, const uint32_t (&q)[16]) {
-        uint32_t *dst = ringRow + ((rel - cur0) & 31u);
+        uint32_t *dst = ringRow + (rel & 31u);
 #pragma unroll
         for (int i = 0; i < 16; i++) dst[i] = q[i];
     };
@@ -728,15 +727,18 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
         for (int i = 0; i < 16; i++) ringRow[i] = sw[i];
     }
     asm volatile("" ::: "memory");
-    E.F = cur0 + 16;
+    // from here on word indices are relative to the first word staged (cur0): ring slot = index & 31 with no subtraction in
+    // the per-residual path; bit positions follow (bit0R may wrap below zero: only differences are used)
+    const uint64_t wordBaseR = wordBase + cur0;
+    const uint32_t bit0R = bit0 - cur0 * 32u;
+    E.F = 16;
     {
         E.bw.ring = ringRow;
         E.bw.w0 = ringRow[0];
         E.bw.w1 = ringRow[1];
         E.bw.o = pos0 & 31;
-        E.bw.idx = cur0 + 2;
+        E.bw.idx = 2;
         E.bw.nw = ringRow[2];
-        E.bw.org = cur0;
     }
     E.active = coded ? 1u : 0u;
     E.chan = 0;
@@ -750,9 +752,9 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
 
     uint32_t *prog = (PUB && live) ? (LOCAL ? progLds + lane * 2 : V.prog + (uint64_t)p * 2) : nullptr;
     if (__all(!coded || (pbU == 40 && pbV == 40)))
-        entropy_rounds<true, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<true, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBaseR, 0u, bit0R, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
     else
-        entropy_rounds<false, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBase, cur0, bit0, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<false, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBaseR, 0u, bit0R, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
 
     if (live && E.status != status0) {
         rec->status = E.status;
