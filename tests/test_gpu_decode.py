@@ -77,6 +77,41 @@ def test_more_packets_than_a_grid_dimension(gpu_ctx, oracle, frame):
     assert torch.equal(out, d_pcm)
 
 
+def test_large_ragged_batch_in_the_separate_launch_regime(gpu_ctx, oracle):
+    """40 000 stereo packets (80 000 chains: the separate-launch decode regime with its work lists) whose lengths are
+    drawn per packet — full frames, lengths that are not multiples of four, and lengths below 16 samples, which the
+    one-lane predictor does not take (generic predictor + k_dec_unmix's leftover list) — mixed with the generator's
+    silent, noisy (uncompressed) and tonal classes: every packet's valid frames must come back, oracle bytes on a sample"""
+    import torch
+    frame, n = 256, 40000
+    fmt = alac_amd.make_format(frame, 16, 2)
+    rng = np.random.default_rng(77)
+    ns = np.full(n, frame, np.int32)
+    pick = rng.random(n)
+    ns[pick < 0.30] = rng.integers(16, frame + 1, int((pick < 0.30).sum()))
+    ns[pick < 0.05] = rng.integers(1, 16, int((pick < 0.05).sum()))
+    d_pcm = gpu_ctx.synth_pcm(0, n, fmt)
+    d_ns = torch.from_numpy(ns).cuda()
+    b = gpu_ctx.encode(fmt, d_pcm, n, num_samples=d_ns)
+    gpu_ctx.synchronize()
+    offs = b["offsets"].cpu().numpy()
+    stream = b["out"][:int(offs[-1])].cpu().numpy()
+    pcm = d_pcm.cpu().numpy()
+    enc = oracle.encoder(frame, 16, 2)
+    for p in list(range(0, n, 997)) + [n - 1] + [int(i) for i in np.nonzero(ns < 16)[0][:8]]:
+        enc.reset()
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * 4], int(ns[p]))
+        assert np.array_equal(stream[offs[p]:offs[p + 1]], pk), p
+    out, dns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), b["out"], b["offsets"], n)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and torch.equal(dns.to(torch.int32), d_ns)
+    got = out.view(torch.int32).reshape(n, frame)
+    want = d_pcm.view(torch.int32).reshape(n, frame)
+    valid = torch.arange(frame, device="cuda")[None, :] < d_ns[:, None]
+    bad = ((got != want) & valid).any(dim=1)
+    assert not bool(bad.any()), ("packets differ", torch.nonzero(bad)[:8].flatten().tolist(), ns[torch.nonzero(bad)[:8].flatten().cpu().numpy()])
+
+
 def _bits(value, width):
     return [(value >> (width - 1 - i)) & 1 for i in range(width)]
 
