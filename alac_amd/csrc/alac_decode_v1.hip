@@ -3,14 +3,22 @@
 //
 //   k_dec_stage      copy of the packed stream into 32-bit words, MSB first (byte swapped), zero padded: the
 //                    bit readers below then work on aligned words and may over-read safely
-//   k_dec_entropy    one lane per packet: element/header parse (codec/ALACDecoder.cu:571-1002), then dyn_decomp
-//                    (codec/ag_dec.c:272-362) of U and V — or the raw samples of an escape element — from a
-//                    64-bit register bit window refilled out of a per-lane LDS ring; the ring is re-staged from
-//                    the word stream every 16 symbols with 16-byte loads issued a round ahead.  The channel that
-//                    is decoded is serial by nature (V starts where U's bits end): the parallelism is 10 000
-//                    packets wide, and a symbol costs ~70 instructions instead of ~5 dependent byte loads.
-//   k_dec_unpc       unpc_block (codec/dp_dec.c:55-381), in place
-//   k_dec_unmix      un-mix + shift-byte re-attach + PCM packing (codec/ALACDecoder.cu:193-563)
+//   k_dec_header     one lane per packet: element / header parse (codec/ALACDecoder.cu:571-1002): record, payload
+//                    position, status; who writes the packet's PCM (DecRec::pad2); in the separate-launch regime the
+//                    work lists of the kernels below (dec_lists)
+//   entropy lanes    dyn_decomp (codec/ag_dec.c:272-362) of U and V, one lane per packet, from a 64-bit register bit
+//                    window refilled out of a per-lane LDS ring that is re-staged from the word stream every 16
+//                    residuals with 16-byte loads issued a round ahead.  A packet is serial by nature (V starts where
+//                    U's bits end): the parallelism is the batch, and a residual costs 55 instructions.
+//   predictor        unpc_block (codec/dp_dec.c:55-381): two lanes per chain behind the entropy lanes (unpc_fast_body),
+//                    one lane per chain for large batches (unpc_wide_body, unpc_pair_body), generic lane-serial
+//                    kernel for everything else (k_dec_unpc)
+//   k_dec_raw        uncompressed elements: fixed-width fields, one thread per sample-frame
+//   k_dec_unmix      un-mix + shift-byte re-attach + PCM packing (codec/ALACDecoder.cu:193-563) for the packets whose
+//                    PCM nobody else wrote
+// Two launch shapes (decode_v1_pass): up to 65 536 chains ONE launch k_dec_fused_wg — a workgroup is the entropy wave of
+// 48 packets and the three predictor waves that follow it through its rows (workgroup-scope hand-off, LDS progress
+// words); above that k_dec_raw, k_dec_entropy_wide, k_dec_unpc_wide as separate launches that each fill the machine.
 //
 // Sample planes are CHAIN-major here: int32 [packet][channel][frameSize], so every lane streams through its own
 // contiguous row (the entropy lanes drift apart on zero runs, which rules out the sample-major layout of the
