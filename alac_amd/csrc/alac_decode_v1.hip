@@ -922,6 +922,9 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
 #pragma unroll
         for (int q = 0; q < 4; q++) ((int4 *)row)[q] = make_int4(o16[4 * q], o16[4 * q + 1], o16[4 * q + 2], o16[4 * q + 3]);
     }
+    // (measured and not kept: hiding the lane-constant AND masks of the step from the compiler turns its v_mov_b32_dpp +
+    // select pairs into v_and_b32_dpp — 59 -> 57 instructions per step — and the launch gets SLOWER, 1.655 -> 1.731 ms at
+    // 10 000 packets: the fused form puts the DPP wait states on the dependent chain)
     const LmsDecLane L = make_dec_lane(lane, na);
     int32_t a[4], w[4], tp;
 #pragma unroll
