@@ -3,7 +3,7 @@
 // lockstep over the sample index.
 //
 // What differs from the plain restatement in alac_dev.hpp (same bits out):
-//   * the symbol's quotient n / m with m = 2^k - 1 is table-free: two shift-and-add levels (golf_sym), exact on the only
+//   * the symbol's quotient n / m with m = 2^k - 1 is table-free: two add-and-shift rounds (golf_sym), exact on the only
 //     branch that uses it (n < 9 m); only the rare run-length code (golf_close_run) still takes a multiply-high by the
 //     tabulated reciprocal ceil(2^32 / m) — exact there because nz < 2^16 and m < 2^8;
 //   * pb is the encoder's constant 40 (= (pbFactor 4 * PB0 40) / 4, codec/ALACEncoder.cu:365,515), so
@@ -194,15 +194,16 @@ __device__ __forceinline__ void golf_sym(GolF &g, int32_t del, bool valid, uint3
         const uint32_t m = (1u << k) - 1;
         const uint32_t n = t2 - g.zmode;
         const bool esc = n >= m * 9;  // div >= MAX_PREFIX_32
-        // n / m for m = 2^k - 1, needed only when n < 9 m.  With n = q0 2^k + r0 = q0 m + (q0 + r0) and
-        // t0 = q0 + r0 = q1 2^k + r1 = q1 m + (q1 + r1): n / m = q0 + q1 + [q1 + r1 >= m] for every k >= 2
-        // (q0 <= 8 keeps q1 + r1 < 2 m); m = 1 is the identity.  No table, no division.
-        const uint32_t q0 = n >> k;
-        const uint32_t t0 = q0 + (n & m);
-        const uint32_t q1 = t0 >> k;
-        const uint32_t t1 = q1 + (t0 & m);
-        uint32_t div = q0 + q1 + (t1 >= m ? 1u : 0u);
-        div = k == 1 ? n : div;
+        // n / m for m = 2^k - 1, needed only when n < 9 m (d = n / m <= 8): two rounds of "add the previous estimate and
+        // shift" — d1 = (n + (n >> k) + 1) >> k, div = (n + d1 + 1) >> k — five instructions, no table, no division, no
+        // k == 1 case.  Since n + 1 = d 2^k + (r + 1 - d) with 0 <= r < m, adding an estimate e of d in [d - 1, d] lands
+        // in [d 2^k, (d + 1) 2^k); n >> k is within 1 of d for k >= 3 and the second round repairs k = 2.  For k = 1
+        // (m = 1) div can still come out one short at n = 7, 8 — and the code is the SAME: with m = 1 a short div only
+        // moves a one from the unary part into the remainder field.  Every (k, n) of the range is enumerated by
+        // tests/test_coder_division.py (quotient for k >= 2, emitted (numBits, value) for k >= 1).
+        // (Round 3: this replaced a two-level shift-and-add with a select for k = 1: thirteen instructions.)
+        const uint32_t d1 = (n + (n >> k) + 1u) >> k;
+        const uint32_t div = (n + d1 + 1u) >> k;
         const uint32_t mod = n - __umul24(div, m);
         // dyn_code_32bit (:151-183): numBits = div + k + 1 - [mod == 0], value = ones(div) 0 (mod + 1 - [mod == 0])
         const uint32_t ne = min(mod, 1u);
