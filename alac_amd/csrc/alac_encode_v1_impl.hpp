@@ -431,7 +431,7 @@ __device__ __forceinline__ void load_ops(StepOps &o, const int32_t *pn, const in
     }
 }
 
-template <int T, int LPC, bool MASKED>
+template <int T, int LPC, bool MASKED, bool DEAD = (T > 4)>
 __device__ __forceinline__ void run_block(int32_t (&a)[T], int32_t (&w)[T], const StepOps &o, const LmsLaneT<T> &L, int jb,
                                           int32_t *resAt, uint32_t chanbits)
 {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void run_block(int32_t (&a)[T], int32_t (&w)[T], cons
     for (int s = 0; s < 8; s++) {
         const int j = jb + s;
         const int32_t liveMask = MASKED ? (((j >= L.jlo) & (j < L.jhi)) ? -1 : 0) : -1;
-        resAt[s] = lms_step<T, LPC, MASKED>(a, w, o.tp[s], o.cu[s], liveMask, L, chanbits);
+        resAt[s] = lms_step<T, LPC, MASKED, DEAD>(a, w, o.tp[s], o.cu[s], liveMask, L, chanbits);
 #pragma unroll
         for (int i = T - 1; i > 0; i--) w[i] = w[i - 1];
         w[0] = o.nx[s];
@@ -455,7 +455,7 @@ struct LaneView {
 };
 
 // one tile [j0, jEnd) of steps; the history windows are (re)loaded from LDS at the tile start
-template <int T, int LPC>
+template <int T, int LPC, bool DEAD = (T > 4)>
 __device__ __forceinline__ void run_tile(int32_t (&a)[T], const LaneView &V, const LmsLaneT<T> &L, int j0, int jEnd,
                                          uint32_t chanbits)
 {
@@ -474,9 +474,9 @@ __device__ __forceinline__ void run_tile(int32_t (&a)[T], const LaneView &V, con
         load_ops(nxt, pn + adv * (o + 8), pt + adv * (o + 8), pc + (o + 8));
         const bool allLive = __all((jb >= L.jlo) & (jb + 8 <= L.jhi));  // wave-uniform
         if (allLive)
-            run_block<T, LPC, false>(a, w, cur, L, jb, V.res + o, chanbits);
+            run_block<T, LPC, false, DEAD>(a, w, cur, L, jb, V.res + o, chanbits);
         else
-            run_block<T, LPC, true>(a, w, cur, L, jb, V.res + o, chanbits);
+            run_block<T, LPC, true, DEAD>(a, w, cur, L, jb, V.res + o, chanbits);
     };
     for (int jb = j0; jb < jEnd; jb += 16) {
         block(opA, opB, jb);
@@ -500,7 +500,7 @@ struct ChainJob {
 // sink(j0, row) called once per tile with the lane's own LDS row (row[i] = residual of position j0 + i, i < TILE; only
 // meaningful for LPC = 1 where lane == slot): the residuals never leave the CU (k_class_final).
 struct NoSink {};
-template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false, int T = 4, class Sink = NoSink>
+template <int DEPTH, int CH, int LPC, bool WT = false, bool ZZ = false, int T = 4, class Sink = NoSink, bool DEAD = (T > 4)>
 __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, const ChainJob &J, int32_t (&a)[T],
                                          uint32_t num, uint32_t P, bool store, int32_t *dst, uint64_t streamStride,
                                          uint32_t stream, int lane, uint32_t *flag = nullptr, uint32_t flagBase = 0,
@@ -575,7 +575,7 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
             lds_order();
         }
         const int jEnd = min(j0 + Geo<LPC>::TILE, (int)((runTo + 7) & ~7u));
-        run_tile<T, LPC>(a, V, L, j0, jEnd, chanBits);
+        run_tile<T, LPC, DEAD>(a, V, L, j0, jEnd, chanBits);
         lds_order();
         if (store) {
             if (j0 == 0) {
@@ -1470,7 +1470,7 @@ __global__ __launch_bounds__(64, 2) void k_search1_lane(V1Args A, uint32_t chanB
         golf_reset(g);
         CoderSink<false, false> sink{g, n8, nMax, nMin, chanBits, recip};
         // only the last pass (mixRes = 4) also leaves its residuals in HBM: k_search2_lane counts its tail
-        lms_pass<DEPTH, 2, 1, false, false, 8, CoderSink<false, false>>(sh, A, J, a, J.N / 8, J.N / 8, true, r == kMaxRes ? A.resA : nullptr,
+        lms_pass<DEPTH, 2, 1, false, false, 8, CoderSink<false, false>, false>(sh, A, J, a, J.N / 8, J.N / 8, true, r == kMaxRes ? A.resA : nullptr,
                                                                         5ull * A.chainsPad, (uint32_t)r * A.chainsPad + chain, lane,
                                                                         nullptr, 0, nullptr, 0, &sink);
         golf_finish<false>(g, n8 > 0, recip);
@@ -1511,10 +1511,10 @@ __device__ __forceinline__ void search2_lane_body(LmsShared<1> &sh, const uint32
         const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
         if (last) {
             CoderSink<false, false> sink{g, P2, wave_max(P2), wave_min_u32(P2), chanBits, recip};
-            lms_pass<DEPTH, CH, 1, false, false, T, CoderSink<false, false>>(sh, A, J, a, num, P2, true, nullptr, 0, chain, lane, nullptr, 0,
+            lms_pass<DEPTH, CH, 1, false, false, T, CoderSink<false, false>, false>(sh, A, J, a, num, P2, true, nullptr, 0, chain, lane, nullptr, 0,
                                                                              nullptr, 0, &sink);
         } else {
-            lms_pass<DEPTH, CH, 1, false, false, T>(sh, A, J, a, num, 0, false, nullptr, 0, chain, lane);
+            lms_pass<DEPTH, CH, 1, false, false, T, NoSink, false>(sh, A, J, a, num, 0, false, nullptr, 0, chain, lane);
         }
     }
     store_row<1, T>(J, a, lane);

@@ -100,7 +100,9 @@ __device__ __forceinline__ LmsLaneT<T> make_lane(int lane, int na, int num)
 //   tp    in[j-1-na] ("top"),  cu = in[j]
 // Returns the residual.  sum1 = (denhalf - sum) >> 9 and del = in[j] - top - sum1 (dp_enc.c:136-139)
 // are folded into del = (in[j] - top) + ((sum + 255) >> 9): -floor((256 - s)/512) == floor((s + 255)/512).
-template <int T, int L, bool MASKED>
+// DEAD: the lane may hold taps beyond its row's own count (a 4-tap row in an 8-tap lane: k_class_final<.., 8>); kernels whose
+// rows always fill the lane (the in-lane searches) pass false and save the mask per tap
+template <int T, int L, bool MASKED, bool DEAD = (T > 4)>
 __device__ __forceinline__ int32_t lms_step(int32_t (&a)[T], const int32_t (&w)[T], int32_t tp, int32_t cu,
                                             int32_t liveMask, const LmsLaneT<T> &R, uint32_t chanbits)
 {
@@ -134,7 +136,7 @@ __device__ __forceinline__ int32_t lms_step(int32_t (&a)[T], const int32_t (&w)[
         // A lane that holds no active tap at all is fed zeros (b = 0: nothing happens).  With 8 taps in one lane a 4-tap
         // row (the narrower channel of a packet of the 8-tap class) has dead taps BESIDE live ones: their window holds
         // real samples, so their sign is forced to 0 — then t = 0, the coefficient stays 0 and the tap sum ignores it.
-        if constexpr (T > 4) sb[i] &= R.act[i];
+        if constexpr (DEAD) sb[i] &= R.act[i];
         t[i] = (uint32_t)(__mul24(sb[i], b[i]) + rc) >> kDenShift;  // |b| = sign(b) * b
     }
     int32_t S[T];  // in-lane part of S_k, from the top tap down
