@@ -73,6 +73,11 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  *   "idlefast", "wide81" (-1/0/1), "split_coder", "overlap_pos", "pubfence" (0/1), "subbatch" (0..8), "persist" (-1/0/1)
  *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels
  *   "dec_fused" (-1/0/1), "dec_wide" (0/1), "dec_pair" (0/1), "dec_local" (0/1), "dec_pubmask" (-1 = auto)   decode launch shape
+ *   "class_fused", "search_fused" (0/1), "thru_wg4" (0/1)   throughput regime: predictor + coder of a chain in one lane (final
+ *                          pass / searches), four waves per workgroup
+ *   "fold" (bit mask), "count_walk" (0/1), "init_state" (0/1), "lds_pad"   latency regime: launches folded into their
+ *                          neighbours, the mixRes count as a walking consumer, workspace rows always initialised, LDS padding
+ *   "fast_mode" (0/1)      ALACEncoder::SetFastMode: the search-free stereo path (EncodeStereoFast)
  *   "stage_taps" (0/1)     alac_hip_pc_block: tap-parallel kernel for 5..30 taps
  *   "debug_lose_handoff" (0/1)  test switch: producers of the in-launch hand-offs never publish
  * Every setting produces the same bytes; only the kernels that run differ.  Unknown key -> kALAC_ParamError. */
