@@ -77,6 +77,21 @@ def test_more_packets_than_a_grid_dimension(gpu_ctx, oracle, frame):
     assert torch.equal(out, d_pcm)
 
 
+@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("n", [1, 47, 48, 49, 95, 96, 97, 145])
+def test_packet_counts_around_the_entropy_wave_size(gpu_ctx, channels, n):
+    """the fused decode launch gives an entropy wave 48 packets and its three follower waves 32 chains each: batch sizes on
+    both sides of those boundaries, mono (48 chains per workgroup: one and a half followers) and stereo, round trip exact"""
+    import torch
+    fmt = alac_amd.make_format(512, 16, channels)
+    d_pcm = gpu_ctx.synth_pcm(3, n, fmt)
+    b = gpu_ctx.encode(fmt, d_pcm, n)
+    out, ns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), b["out"], b["offsets"], n)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and int((ns != 512).sum()) == 0
+    assert torch.equal(out, d_pcm)
+
+
 def test_large_ragged_batch_in_the_separate_launch_regime(gpu_ctx, oracle):
     """40 000 stereo packets (80 000 chains: the separate-launch decode regime with its work lists) whose lengths are
     drawn per packet — full frames, lengths that are not multiples of four, and lengths below 16 samples, which the
