@@ -80,7 +80,19 @@ SIGNATURES = {
     "alac_hip_synth_pcm": (_i32, [_vp, _u64, _u32, C.POINTER(Format), _vp]),
     "alac_hip_shard_range": (_i32, [_u64, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "alac_hip_shard_offsets": (_i32, [_vp, _u32, _vp]),
+    "alac_hip_comm_unique_id": (_i32, [_vp]),
+    "alac_hip_comm_create": (_i32, [C.POINTER(_vp), _i32, _vp, _u32, _u32]),
+    "alac_hip_comm_destroy": (None, [_vp]),
+    "alac_hip_comm_rank": (_u32, [_vp]),
+    "alac_hip_comm_world": (_u32, [_vp]),
+    "alac_hip_comm_last_error": (C.c_char_p, [_vp]),
+    "alac_hip_reassemble_begin": (_i32, [_vp, _u32, _vp, _u64, _u64, _vp, _u32, _vp, _vp]),
+    "alac_hip_reassemble_finish": (_i32, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "alac_hip_reassemble": (_i32, [_vp, _vp, _vp, _u64, _vp, _u32, _vp, _vp, _u64, _vp, _vp]),
 }
+
+COMM_ID_BYTES = 128
+COMM_SLOTS = 4
 
 _lib = None
 
@@ -415,3 +427,55 @@ class Context:
             for x in (pc, nb, st):
                 x.record_stream(cur)  # allocated on self.stream, consumed on the caller's
             return pc, nb, st
+
+
+class Comm:
+    """One alac_hip_comm (RCCL communicator of the re-assembly, include/alac_hip.h): one per process / GPU.
+
+    `unique_id()` on rank 0 -> bytes every rank passes to the constructor (distributed by the caller's launcher channel).
+    begin() / finish() enqueue on the torch stream that is current when they are called and never touch torch.distributed."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = load_library().alac_hip_comm_unique_id(buf)
+        if rc != 0:
+            raise AlacError(rc, "alac_hip_comm_unique_id (librccl missing?)")
+        return bytes(buf)
+
+    def __init__(self, device, unique_id, rank, world):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        self.device = torch.device("cuda", device)
+        h = _vp()
+        idb = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        rc = self.lib.alac_hip_comm_create(C.byref(h), device, idb, rank, world)
+        if rc != 0:
+            raise AlacError(rc, "alac_hip_comm_create failed")
+        self.h, self.rank, self.world = h, rank, world
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.alac_hip_comm_destroy(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AlacError(rc, self.lib.alac_hip_comm_last_error(self.h).decode())
+
+    def _stream(self):
+        return _vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def begin(self, slot, offsets, num_packets, shard_capacity, out_capacity, sizes=None, all_sizes=None):
+        """offsets: the int64 [num_packets + 1] tensor alac_hip_encode wrote (its last entry is the shard's byte count)"""
+        self._check(self.lib.alac_hip_reassemble_begin(
+            self.h, slot, offsets.data_ptr() + 8 * num_packets, int(shard_capacity), int(out_capacity),
+            None if sizes is None else sizes.data_ptr(), num_packets, None if all_sizes is None else all_sizes.data_ptr(),
+            self._stream()))
+
+    def finish(self, slot, shard, stream_out):
+        """-> byte offsets of the shards in stream_out, [world + 1]"""
+        offs = (_u64 * (self.world + 1))()
+        self._check(self.lib.alac_hip_reassemble_finish(self.h, slot, shard.data_ptr(), stream_out.data_ptr(), offs, self._stream()))
+        return list(offs)

@@ -176,6 +176,7 @@ struct EncLayout {
     // tap-parallel pipeline: residual planes [sample][stream], decision scratch, working state
     uint64_t resA, resB, resC, bits1, cost2, state, flags, rowReady, cls, colChain;
     uint64_t bitWordsB, bitsB;  // tiny batches only (0: absent): second coder wave of the split final coder
+    uint64_t segBad;            // one word: k_check_segments refused the caller's segment table (EncodeArgs::segBad)
     uint32_t chainsPad, colsPad;
 };
 
@@ -239,6 +240,8 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
         L.bitsB = off;
         off = align_up(off + ((uint64_t)numPackets + 1) * 2 * 4, 256);
     }
+    L.segBad = off;
+    off += 256;
     L.total = off;
     return L;
 }
@@ -679,6 +682,11 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
     ea.wcap = L.wcap;
     ea.recs = (PacketRec *)(ws + L.recs);
     ea.packetBytes = d_packet_bytes;
+    // a table with the caller's bound (alac_hip_encode_segmented) is not read back: the kernels test every entry they use
+    const bool unread = d_seg_first && maxSegHint;
+    ea.numPackets = num_packets;
+    ea.segMax = unread ? (maxSegHint < num_packets ? maxSegHint : num_packets) : 0xffffffffu;
+    ea.segBad = unread ? (uint32_t *)(ws + L.segBad) : nullptr;
     PackArgs pa;
     pa.pcm = ea.pcm;
     pa.recs = ea.recs;
@@ -687,15 +695,16 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
     pa.frameSize = fmt->frame_size;
     pa.offsets = d_packet_offsets;
     pa.out = d_out;
+    pa.segBad = ea.segBad;
     constexpr uint32_t EV = (kMaxSubBatches + 1) * (kNumStages + 1);
     hipEvent_t *ev = nullptr;
     if (timed && ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size())
         ev = &ctx->events[ctx->profCalls++ * EV];
     hipError_t e;
     // the caller's bound on the segment length (alac_hip_encode_segmented) is checked on the device whatever kernels run
-    if (d_seg_first && maxSegHint)
-        launch_check_segments(d_seg_first, num_segments, num_packets, maxSegHint < num_packets ? maxSegHint : num_packets,
-                              ctx->errDev ? ctx->errDev + 1 : nullptr, ctx->stream);
+    if (unread)
+        launch_check_segments(d_seg_first, num_segments, num_packets, ea.segMax, ctx->errDev ? ctx->errDev + 1 : nullptr,
+                              ea.segBad, ctx->stream);
     if (use_lane_encoder(ctx)) {
         if (ev) ctx->profSub.push_back(0);
         e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream,

@@ -456,35 +456,35 @@ __device__ void pc_general(const int32_t *in, int32_t *pc, int32_t num, int16_t 
         return;
     }
     if (na == 31) {
-        for (int32_t j = 1; j < num; j++) pc[j] = sext(in[j] - in[j - 1], chanshift);
+        for (int32_t j = 1; j < num; j++) pc[j] = sext(wsub(in[j], in[j - 1]), chanshift);
         return;
     }
-    for (int32_t j = 1; j <= na; j++) pc[j] = sext(in[j] - in[j - 1], chanshift);
+    for (int32_t j = 1; j <= na; j++) pc[j] = sext(wsub(in[j], in[j - 1]), chanshift);
     int32_t a[32];
     for (int32_t k = 0; k < 32; k++) a[k] = k < na ? coefs[k] : 0;
     for (int32_t j = na + 1; j < num; j++) {
         const int32_t top = in[j - na - 1];
         const int32_t *pin = in + j - 1;
         int32_t sum = 0;
-        for (int32_t k = 0; k < na; k++) sum -= a[k] * (top - pin[-k]);
-        const int32_t del = sext(in[j] - top - ((sum + denhalf) >> denshift), chanshift);
+        for (int32_t k = 0; k < na; k++) sum = wsub(sum, wmul(a[k], wsub(top, pin[-k])));
+        const int32_t del = sext(wsub(wsub(in[j], top), wadd(sum, denhalf) >> denshift), chanshift);
         pc[j] = del;
         int32_t del0 = del;
         const int32_t sg = sign_of(del);
         if (sg > 0) {
             for (int32_t k = na - 1; k >= 0; k--) {
-                const int32_t dd = top - pin[-k];
+                const int32_t dd = wsub(top, pin[-k]);
                 const int32_t sgn = sign_of(dd);
                 a[k] = (int16_t)(a[k] - sgn);
-                del0 -= (na - k) * ((sgn * dd) >> denshift);
+                del0 = wsub(del0, wmul(na - k, wmul(sgn, dd) >> denshift));
                 if (del0 <= 0) break;
             }
         } else if (sg < 0) {
             for (int32_t k = na - 1; k >= 0; k--) {
-                const int32_t dd = top - pin[-k];
+                const int32_t dd = wsub(top, pin[-k]);
                 const int32_t sgn = sign_of(dd);
                 a[k] = (int16_t)(a[k] + sgn);
-                del0 -= (na - k) * ((-sgn * dd) >> denshift);
+                del0 = wsub(del0, wmul(na - k, wmul(-sgn, dd) >> denshift));
                 if (del0 >= 0) break;
             }
         }

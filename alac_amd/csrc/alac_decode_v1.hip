@@ -31,6 +31,7 @@
 
 namespace alacdev {
 
+constexpr uint32_t kFastChanBits = 23;  // widest sample the __mul24 predictor bodies take (see k_dec_header)
 constexpr int kDecRound = 16;    // symbols decoded between two restagings of the LDS ring
 constexpr int kWinWords = 16;    // words staged per lane per round (64 bytes)
 constexpr int kWinStride = 33;   // LDS words per lane: a circular ring of 32 (+1: odd stride, conflict-free columns)
@@ -309,7 +310,10 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     // who writes this packet's PCM: the predictor lanes of a pair or k_dec_raw (pad2 = 1), or k_dec_unmix
     const bool good = live && status == 0;
     const bool stereo16 = dec_stereo16(V);
-    const bool fastShape = (A.frameSize & 7) == 0 && R.numSamples >= 16 && haveElement && !R.escape;  // unpc_fast_ok
+    // unpc_fast_ok; chanBits <= 23: the fast predictor bodies multiply coefficient x (top - sample) with 24-bit multiplies,
+    // and a difference of two chanBits-wide samples has chanBits + 1 significant bits (24-bit material coded without
+    // shift-off bytes, 32-bit mono: the generic predictor's job)
+    const bool fastShape = (A.frameSize & 7) == 0 && R.numSamples >= 16 && haveElement && !R.escape && chanBits <= kFastChanBits;
     const bool ok0 = good && fastShape && okc[0], ok1 = good && fastShape && R.elementChannels == 2 && okc[1];
     const bool pair = stereo16 && V.lists && V.pairs && ok0 && ok1;
     const bool rawP = good && haveElement && R.escape != 0;
@@ -338,7 +342,6 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     }
     (void)pbU;
     (void)pbV;
-    (void)chanBits;
 }
 
 // ---- k_dec_raw: uncompressed (escape) elements are fixed-width fields, i.e. not serial at all: one thread per
@@ -798,8 +801,9 @@ __device__ __forceinline__ bool unpc_fast_ok(const DecodeArgs &A, const DecRec *
 {
     if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return false;
     const DecChan &c = rec->c[ch];
+    const uint32_t chanBits = A.bitDepth - rec->bytesShifted * 8 + (rec->elementChannels == 2 ? 1 : 0);
     return (A.frameSize & 7) == 0 && rec->numSamples >= 16 && c.mode == 0 && c.denShift == kDenShift &&
-           (c.num == 4 || c.num == 8);
+           (c.num == 4 || c.num == 8) && chanBits <= kFastChanBits;
 }
 
 // the first 16 samples (warm-up positions + a few regular steps), lane-serial; leaves coefficients and outputs

@@ -37,6 +37,15 @@ __device__ __forceinline__ int32_t sext(int32_t x, uint32_t chanshift)
     return (int32_t)((uint32_t)x << chanshift) >> chanshift;
 }
 __device__ __forceinline__ int32_t sign_of(int32_t x) { return min(max(x, -1), 1); }
+// Two's-complement wrap-around made explicit.  The reference's int32 predictor arithmetic overflows for full-scale 32-bit
+// material (chanBits 32: a difference of two samples has 33 significant bits) and its compiled objects wrap (the oracle pins
+// exactly that, -fwrapv); signed overflow in device code is undefined, and the compiler uses that — sign_of(top - x) became
+// a comparison of top with x.  Every generic predictor form (any chanBits) computes with these; the hot fast paths are
+// restricted to chanBits <= 23, where no difference can overflow.
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+__device__ __forceinline__ int32_t wabs(int32_t a) { return a < 0 ? wsub(0, a) : a; }
 // x * 5 as one shift-add (the compiler turns (x << 2) + x back into a quarter-rate 32-bit multiply)
 __device__ __forceinline__ uint32_t times5(uint32_t x)
 {
@@ -124,20 +133,19 @@ __device__ __forceinline__ int32_t lms_step_enc(Lms<NA> &s, int32_t x, uint32_t 
     int32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < NA; k++) {
-        b[k] = top - s.h[k];
-        sum += s.a[k] * b[k];
+        b[k] = wsub(top, s.h[k]);
+        sum = wadd(sum, wmul(s.a[k], b[k]));
     }
-    int32_t del = sext(x - top - (((1 << (kDenShift - 1)) - sum) >> kDenShift), chanshift);
+    int32_t del = sext(wsub(wsub(x, top), wsub(1 << (kDenShift - 1), sum) >> kDenShift), chanshift);
 
     const int32_t sgd = (del > 0) - (del < 0);
-    int32_t e = del < 0 ? -del : del;
+    int32_t e = wabs(del);
     const int32_t off = del < 0 ? 511 : 0;
 #pragma unroll
     for (int k = NA - 1; k >= 0; k--) {
         const int32_t d = (e > 0) ? sgd * sign_of(b[k]) : 0;
         s.a[k] = (int16_t)(s.a[k] - d);
-        const int32_t ab = b[k] < 0 ? -b[k] : b[k];
-        e -= (NA - k) * ((ab + off) >> kDenShift);
+        e = wsub(e, wmul(NA - k, wadd(wabs(b[k]), off) >> kDenShift));
     }
     lms_push<NA>(s, x);
     return del;
@@ -154,21 +162,20 @@ __device__ __forceinline__ int32_t lms_step_dec(Lms<NA> &s, int32_t del, uint32_
     int32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < NA; k++) {
-        b[k] = top - s.h[k];
-        sum += s.a[k] * b[k];
+        b[k] = wsub(top, s.h[k]);
+        sum = wadd(sum, wmul(s.a[k], b[k]));
     }
     const int32_t denhalf = denshift ? (1 << (denshift - 1)) : 0;
-    const int32_t out = sext(del + top + ((denhalf - sum) >> denshift), chanshift);
+    const int32_t out = sext(wadd(wadd(del, top), wsub(denhalf, sum) >> denshift), chanshift);
 
     const int32_t sgd = (del > 0) - (del < 0);
-    int32_t e = del < 0 ? -del : del;
+    int32_t e = wabs(del);
     const int32_t off = del < 0 ? ((1 << denshift) - 1) : 0;
 #pragma unroll
     for (int k = NA - 1; k >= 0; k--) {
         const int32_t d = (e > 0) ? sgd * sign_of(b[k]) : 0;
         s.a[k] = (int16_t)(s.a[k] - d);
-        const int32_t ab = b[k] < 0 ? -b[k] : b[k];
-        e -= (NA - k) * ((ab + off) >> denshift);
+        e = wsub(e, wmul(NA - k, wadd(wabs(b[k]), off) >> denshift));
     }
     lms_push<NA>(s, out);
     return out;

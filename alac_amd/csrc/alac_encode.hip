@@ -146,8 +146,9 @@ __global__ __launch_bounds__(64) void k_encode_stereo(EncodeArgs A)
         for (int k = 4; k < 8; k++) a7[k] = 0;
     }
 
-    const uint32_t p0 = A.segFirst ? A.segFirst[seg] : seg;
+    uint32_t p0 = A.segFirst ? A.segFirst[seg] : seg;
     const uint32_t p1 = A.segFirst ? A.segFirst[seg + 1] : seg + 1;
+    if (p1 < p0 || p1 > A.numPackets || p1 - p0 > A.segMax) p0 = p1;  // unvalidated table (EncodeArgs::segMax): no packets
     int32_t *pred = A.pred + gl;  // [j][lane] so a wave's stores coalesce
     const uint64_t predStride = A.predStride;
 
@@ -299,8 +300,9 @@ __global__ __launch_bounds__(64) void k_encode_mono(EncodeArgs A)
         for (int k = 4; k < 8; k++) a7[k] = 0;
     }
 
-    const uint32_t p0 = A.segFirst ? A.segFirst[seg] : seg;
+    uint32_t p0 = A.segFirst ? A.segFirst[seg] : seg;
     const uint32_t p1 = A.segFirst ? A.segFirst[seg + 1] : seg + 1;
+    if (p1 < p0 || p1 > A.numPackets || p1 - p0 > A.segMax) p0 = p1;  // unvalidated table (EncodeArgs::segMax): no packets
 
     for (uint32_t p = p0; p < p1; p++) {
         uint32_t N = A.numSamples ? A.numSamples[p] : A.frameSize;
@@ -369,18 +371,21 @@ __global__ __launch_bounds__(64) void k_encode_mono(EncodeArgs A)
 // thread t sums sizes[t], sizes[t + 1024], ... (coalesced, independent loads; the sizes sit in L2) — instead of waiting
 // for its predecessors: no scratch memory, no inter-workgroup hand-off, one launch.  The redundant reads are b * 4 KB per
 // workgroup (125 000 packets: 30 MB in all); the single workgroup this replaces took 0.17 ms there.
-__global__ __launch_bounds__(1024) void k_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n)
+__global__ __launch_bounds__(1024) void k_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, const uint32_t *segBad)
 {
+    // a segment table refused on the device (EncodeArgs::segBad): the sizes of packets nobody encoded are whatever the
+    // caller's buffer held — every offset is 0 then and k_pack writes nothing
+    const bool refused = segBad && *segBad != 0;
     __shared__ uint64_t waveSum[16];
     __shared__ uint64_t wavePre[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t base = blockIdx.x * 1024u;
     uint64_t before = 0;
-    for (uint32_t i = tid; i < base; i += 1024) before += sizes[i];
+    for (uint32_t i = tid; i < base; i += 1024) before += refused ? 0u : sizes[i];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
     const uint32_t i = base + tid;
-    const uint64_t v = i < n ? sizes[i] : 0;
+    const uint64_t v = (i < n && !refused) ? sizes[i] : 0;
     uint64_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -457,8 +462,10 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs A, uint32_t numPackets)
     const uint32_t lane = threadIdx.x & 63;
     const bool seamWave = (threadIdx.x >> 6) == (blockDim.x >> 6) - 1;
     constexpr uint32_t SHB = bytes_shifted(DEPTH);
+    const uint32_t refused = A.segBad ? *A.segBad : 0u;  // (requested together with the first record: no extra round trip)
     PacketRec recNext = A.recs[blockIdx.x];
     uint64_t offNext = A.offsets[blockIdx.x];
+    if (refused) return;  // the segment table was refused on the device: records and sizes are not to be trusted
     for (uint32_t p = blockIdx.x; p < numPackets; p += gridDim.x) {
     // this packet's record and offset were requested one packet ago
     const PacketRec rec = recNext;
@@ -902,7 +909,7 @@ static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, con
 {
     if (ev && recordScan) (void)hipEventRecord(ev[kStageScan], st);
     hipLaunchKernelGGL(k_scan_sizes, dim3(numPackets / 1024 + 1), dim3(1024), 0, st, (const uint32_t *)packetBytes, (uint64_t *)pa.offsets,
-                       numPackets);
+                       numPackets, pa.segBad);
     if (ev) (void)hipEventRecord(ev[kStagePack], st);
     // One workgroup of 128 threads per packet (ALAC_HIP_PACK_TPB / ALAC_HIP_PACK_WGS override; with fewer workgroups than
     // packets each walks several).  Measured at 10 000 16-bit packets / 125 000 (tools/dispatch_rate_microbench.hip for the
@@ -921,9 +928,9 @@ static void launch_scan_pack_depth(uint32_t channels, uint32_t *packetBytes, con
     if (ev) (void)hipEventRecord(ev[kNumStages], st);
 }
 
-void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st)
+void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st, const uint32_t *segBad)
 {
-    hipLaunchKernelGGL(k_scan_sizes, dim3(n / 1024 + 1), dim3(1024), 0, st, sizes, offsets, n);
+    hipLaunchKernelGGL(k_scan_sizes, dim3(n / 1024 + 1), dim3(1024), 0, st, sizes, offsets, n, segBad);
 }
 
 void launch_scan_pack(uint32_t depth, uint32_t channels, uint32_t *packetBytes, const PackArgs &pa, uint32_t numPackets,

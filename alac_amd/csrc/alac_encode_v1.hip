@@ -14,19 +14,23 @@ __global__ void k_init_state(int16_t *state, uint32_t numSegments)
     state[i] = (int16_t)(k == 0 ? 1216 : k == 1 ? -928 : k == 2 ? -64 : 0);
 }
 
-__global__ void k_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err)
+__global__ void k_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err,
+                                 uint32_t *segBad)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= numSegments) return;
     const uint32_t a = segFirst[s], b = segFirst[s + 1];
     const bool bad = b < a || b > numPackets || b - a > maxSeg || (s == 0 && a != 0) || (s + 1 == numSegments && b != numPackets);
     if (bad && err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (bad && segBad) *segBad = 1u;  // what the launches behind this one on the stream test (EncodeArgs::segBad)
 }
 
 void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err,
-                           hipStream_t st)
+                           uint32_t *segBad, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_check_segments, dim3((numSegments + 255) / 256), dim3(256), 0, st, segFirst, numSegments, numPackets, maxSeg, err);
+    if (segBad) (void)hipMemsetAsync(segBad, 0, 4, st);
+    hipLaunchKernelGGL(k_check_segments, dim3((numSegments + 255) / 256), dim3(256), 0, st, segFirst, numSegments, numPackets, maxSeg, err,
+                       segBad);
 }
 
 // chains beyond what one 2-lane predictor wave per SIMD holds (1024 SIMDs x 32 chains x 2): throughput regime
@@ -61,6 +65,8 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.S.pos = 0;
     A.S.segBegin = 0;
     A.S.segEnd = ea.numSegments;
+    A.S.numPackets = ea.numPackets;
+    A.S.segMax = ea.segMax;
     A.state = vb.state;
     A.recs = ea.recs;
     A.resA = vb.resA;

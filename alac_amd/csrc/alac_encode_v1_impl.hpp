@@ -61,7 +61,9 @@ __device__ __forceinline__ bool seg_packet(const SegView &S, uint32_t seg, uint3
     const uint32_t p0 = S.segFirst ? S.segFirst[seg] : seg;
     const uint32_t p1 = S.segFirst ? S.segFirst[seg + 1] : seg + 1;
     p = p0 + S.pos;
-    if (p >= p1) {
+    // p1 < p0, p1 > numPackets, a segment longer than promised: the table came from the caller unread
+    // (alac_hip_encode_segmented) — such a segment has no packets, so no index below is ever out of range
+    if (p >= p1 || p1 > S.numPackets || p1 - p0 > S.segMax) {
         p = 0;  // a lane without a packet still forms addresses from p (idle-lane fast paths): keep it in range
         return false;
     }
@@ -1794,10 +1796,11 @@ __global__ __launch_bounds__(64 * WG, 2) void k_class_final(V1Args A, uint32_t c
 
 // packet size + the post-hoc "compressed >= escape -> escape" rule (codec/ALACEncoder.cu:537-543, :952-958)
 template <int DEPTH, int CH>
-__global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numPackets, uint32_t frameSize)
+__global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numPackets, uint32_t frameSize, const uint32_t *segBad)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= numPackets) return;
+    if (segBad && *segBad) return;  // refused segment table: the records of packets nobody encoded are stale
     PacketRec *rec = recs + p;
     constexpr uint32_t SHB = bytes_shifted(DEPTH);
     const uint32_t N = rec->numSamples;
@@ -2070,7 +2073,7 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
     if (evt) (void)hipEventRecord(evt[kStageScan], st);
     if (!latFoldAny)  // (the folded final launches have written the packet sizes)
         hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A0.recs, A0.packetBytes,
-                           numPackets, A0.S.frameSize);
+                           numPackets, A0.S.frameSize, pa.segBad);
     launch_scan_pack(DEPTH, CH, A0.packetBytes, pa, numPackets, st, evt, false);
 }
 

@@ -13,6 +13,7 @@ struct SegView {
     const uint32_t *segFirst;
     uint32_t numSegments, frameSize, pos;
     uint32_t segBegin, segEnd;  // the sub-batch [segBegin, segEnd) this launch works on
+    uint32_t numPackets, segMax;  // bounds every entry of an unvalidated segFirst is tested against (EncodeArgs::segMax)
 };
 
 constexpr uint32_t kNoChain = 0xffffffffu;

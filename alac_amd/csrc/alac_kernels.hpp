@@ -37,6 +37,12 @@ struct EncodeArgs {
     uint32_t wcap;
     PacketRec *recs;
     uint32_t *packetBytes;
+    // alac_hip_encode_segmented hands the segment table over UNVALIDATED (no host read-back): every kernel that forms a
+    // packet index from it tests the entry against these two bounds (a segment that fails them has no packets), and
+    // k_check_segments raises *segBad (device word) for k_finalize / k_scan_sizes / k_pack, which then produce nothing.
+    uint32_t numPackets;
+    uint32_t segMax;             // longest segment the caller promised (0xffffffff: table validated on the host)
+    uint32_t *segBad;            // nullable
 };
 
 struct PackArgs {
@@ -47,6 +53,7 @@ struct PackArgs {
     uint32_t frameSize;
     const uint64_t *offsets;
     uint8_t *out;
+    const uint32_t *segBad;      // nullable; != 0: the segment table was refused on the device — pack nothing
 };
 
 // Stage timing: when `ev` is non-null, ev[i] is recorded BEFORE stage i and ev[kNumStages] after the
@@ -149,6 +156,7 @@ struct V1Streams {
 };
 // *err = 1 (system scope) unless segFirst[0 .. numSegments] ascends inside [0, numPackets] with no step above maxSeg
 void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err,
+                           uint32_t *segBad,
                            hipStream_t st);
 // sub-batches actually used for a batch of numSegments segments
 uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels);
@@ -236,7 +244,7 @@ void launch_mc_tables(const uint32_t *numSamples, uint32_t numPackets, const uin
                       uint32_t count, uint32_t *numSamplesOut, uint32_t *segFirstOut, hipStream_t st);
 // sizes + exclusive scan + bit-granular concatenation of the element packets
 void launch_mc_splice(const McSpliceArgs &a, hipStream_t st);
-void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st);
+void launch_scan_sizes(const uint32_t *sizes, uint64_t *offsets, uint32_t n, hipStream_t st, const uint32_t *segBad = nullptr);
 
 // *count (device) = number of packets whose status is `code`
 hipError_t launch_count_status(const int32_t *status, uint32_t n, int32_t code, uint32_t *count, hipStream_t st);

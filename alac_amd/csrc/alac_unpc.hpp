@@ -26,7 +26,7 @@ __device__ __forceinline__ void unpc_fixed(int32_t *row, uint64_t rs, uint32_t n
             out = del;
             lms_push<NA>(s, out);
         } else if (j <= (uint32_t)NA) {
-            out = sext(del + s.h[0], chanshift);
+            out = sext(wadd(del, s.h[0]), chanshift);
             lms_push<NA>(s, out);
         } else {
             out = lms_step_dec<NA>(s, del, chanshift, denshift);
@@ -49,28 +49,28 @@ __device__ __noinline__ inline void unpc_general(int32_t *row, uint64_t rs, uint
         if (j == 0) {
             out = del;
         } else if (j <= na) {
-            out = sext(del + h[0], chanshift);
+            out = sext(wadd(del, h[0]), chanshift);
         } else {
             const int32_t top = h[na];
             int32_t sum = 0;
-            for (uint32_t k = 0; k < na; k++) sum += a[k] * (h[k] - top);
-            out = sext(del + top + ((sum + denhalf) >> denshift), chanshift);
+            for (uint32_t k = 0; k < na; k++) sum = wadd(sum, wmul(a[k], wsub(h[k], top)));
+            out = sext(wadd(wadd(del, top), wadd(sum, denhalf) >> denshift), chanshift);
             const int32_t sg = sign_of(del);
             int32_t del0 = del;
             if (sg > 0) {
                 for (int32_t k = (int32_t)na - 1; k >= 0; k--) {
-                    const int32_t dd = top - h[k];
+                    const int32_t dd = wsub(top, h[k]);
                     const int32_t sgn = sign_of(dd);
                     a[k] = (int16_t)(a[k] - sgn);
-                    del0 -= ((int32_t)na - k) * ((sgn * dd) >> denshift);
+                    del0 = wsub(del0, wmul((int32_t)na - k, wmul(sgn, dd) >> denshift));
                     if (del0 <= 0) break;
                 }
             } else if (sg < 0) {
                 for (int32_t k = (int32_t)na - 1; k >= 0; k--) {
-                    const int32_t dd = top - h[k];
+                    const int32_t dd = wsub(top, h[k]);
                     const int32_t sgn = sign_of(dd);
                     a[k] = (int16_t)(a[k] + sgn);
-                    del0 -= ((int32_t)na - k) * ((-sgn * dd) >> denshift);
+                    del0 = wsub(del0, wmul((int32_t)na - k, wmul(-sgn, dd) >> denshift));
                     if (del0 >= 0) break;
                 }
             }
@@ -89,7 +89,7 @@ __device__ __forceinline__ void unpc_first_order(int32_t *row, uint64_t rs, uint
     if (!num) return;
     int32_t prev = row[0];
     for (uint32_t j = 1; j < num; j++) {
-        prev = sext(row[(uint64_t)j * rs] + prev, chanshift);
+        prev = sext(wadd(row[(uint64_t)j * rs], prev), chanshift);
         row[(uint64_t)j * rs] = prev;
     }
 }

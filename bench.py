@@ -431,13 +431,60 @@ def encode_leg(torch, alac_amd, ctx, fmt, B, passes=6, warm=2, every=997, with_d
     return out
 
 
+class CabiReassembler:
+    """The re-assembly of bench.py's N > 1 loop on the C-ABI's communicator (alac_amd.Comm -> alac_hip_comm_*,
+    alac_hip_reassemble_begin / _finish): torch.distributed only carries the 128-byte ncclUniqueId to the ranks."""
+
+    def __init__(self, torch, dist, alac_amd, device, rank, world, packets, shard_capacity):
+        idt = torch.zeros(alac_amd.capi.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(alac_amd.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        torch.cuda.synchronize()
+        self.comm = alac_amd.Comm(device, bytes(idt.cpu().numpy().tobytes()), rank, world)
+        self.world, self.packets = world, packets
+        self.stream = torch.empty(world * shard_capacity, dtype=torch.uint8, device="cuda")
+        self.sizes = torch.empty(world * packets, dtype=torch.int32, device="cuda")
+        self.slot = 0
+
+    def begin(self, b):
+        slot, self.slot = self.slot, (self.slot + 1) % alac_amd_slots()
+        self.comm.begin(slot, b["offsets"], self.packets, b["out"].numel(), self.stream.numel(), sizes=b["sizes"],
+                        all_sizes=self.sizes)
+        return slot
+
+    def finish(self, slot, b):
+        offs = self.comm.finish(slot, b["out"], self.stream)
+        return dict(stream=self.stream, total=offs[-1], offsets=offs, sizes=self.sizes,
+                    lens=[offs[r + 1] - offs[r] for r in range(self.world)],
+                    mode="C-ABI: ncclAllGather of the shard table + one ncclSend/ncclRecv group")
+
+
+def alac_amd_slots():
+    from alac_amd.capi import COMM_SLOTS
+    return COMM_SLOTS
+
+
 def rank_main(args):
+    # stdout carries ONE JSON line and nothing else: native libraries write banners to fd 1 (RCCL prints its version block
+    # at the first communicator), so fd 1 points at stderr for the duration of the run and the line goes to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return rank_main_body(args, json_fd)
+    finally:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        os.close(json_fd)
+
+
+def rank_main_body(args, json_fd):
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import alac_amd
-    from alac_amd.reassemble import Reassembler
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -464,16 +511,17 @@ def rank_main(args):
     # oracle legs use, tests/test_gpu_synth.py) and resident in HBM before any timing
     d_pcm = ctx.synth_pcm(first_frame, B, fmt)
     ctx.synchronize()
-    # N > 1: the re-assembly of pass i runs on a side stream under the encode of pass i+1.  It is pipelined in two
-    # phases (alac_amd.reassemble.Reassembler) so that the host never waits for the GPU between two encodes: the
-    # shard lengths of pass i are exchanged right after its encode, the shard bytes one host step later.  Three
-    # output buffer sets rotate because a shard must stay untouched until its sends have run.
+    # N > 1: the re-assembly of pass i runs on a side stream under the encode of pass i+1.  It goes through the C-ABI
+    # (alac_hip_reassemble_begin / _finish, alac_comm.cpp: librccl called from C++, no torch.distributed on the data
+    # path) in two phases so that the host never waits for the GPU between two encodes: the shard lengths of pass i are
+    # exchanged right after its encode, the shard bytes one host step later.  Three output buffer sets rotate because a
+    # shard must stay untouched until its sends have run.
     reassemble = use_dist and not args.no_reassemble
     nbuf = 3 if reassemble else 2
     bufs = [ctx.encode_buffers(fmt, B) for _ in range(nbuf)]
     comm_stream = torch.cuda.Stream() if reassemble else None
-    ra = Reassembler(dist.group.WORLD) if reassemble else None
-    state = {"pending": None, "gather": None, "timing": False, "ev": []}
+    ra = CabiReassembler(torch, dist, alac_amd, local_rank, rank, world, B, bufs[0]["out"].numel()) if reassemble else None
+    state = {"pending": None, "gather": None, "timing": False, "ev": [], "on": reassemble}
 
     def timed(fn):
         """run fn on the current (side) stream between two timing events (kept for reassembly_ms)"""
@@ -491,7 +539,7 @@ def rank_main(args):
             return
         h, b = state["pending"]
         with torch.cuda.stream(comm_stream):
-            state["gather"] = timed(lambda: ra.finish(h))
+            state["gather"] = timed(lambda: ra.finish(h, b))
             done = torch.cuda.Event()
             done.record()
         b["done"] = done  # the buffer set may be encoded into again once this has run
@@ -502,13 +550,13 @@ def rank_main(args):
         if "done" in b:
             torch.cuda.current_stream().wait_event(b.pop("done"))
         ctx.encode(fmt, d_pcm, B, bufs=b)
-        if reassemble:
+        if state["on"]:
             ev = torch.cuda.Event()
             ev.record()
             finish_pending()  # bytes of pass i-1: runs under the encode of pass i just launched
             comm_stream.wait_event(ev)
             with torch.cuda.stream(comm_stream):
-                state["pending"] = (timed(lambda: ra.begin(b["out"], b["offsets"][-1:], b["sizes"])), b)
+                state["pending"] = (timed(lambda: ra.begin(b)), b)
         return b
 
     # the passes are issued ON the context's stream: the events one_pass() records for the hand-over to the RCCL side
@@ -551,6 +599,27 @@ def rank_main(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         reasm_ms = float(t.item())
 
+    # N > 1: the same K steps again WITHOUT the exchange (the --no-reassemble figure), so that one line carries both the
+    # overlapped value and the encode-only value and a scaling curve can be split into encode and RCCL time
+    dt_plain = None
+    if reassemble:
+        state["on"] = False
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(ctx.stream):
+            for i in range(n_pass):
+                one_pass(args.warmup * R + n_pass + i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        dt_plain = float(tp.item())
+        ctx.synchronize()
+        state["on"] = True
+
     total_bytes = int(last["offsets"][-1].item())
 
     # ---- verification legs shared by every rank (after the timed region) -----------------------------------------
@@ -578,7 +647,7 @@ def rank_main(args):
                 and int(gather["sizes"].to(torch.int64).sum().item()) == gather["total"]
             placement = {"shards_at_prefix_sum_offsets": placed, "packet_size_table_consistent": pakt_ok,
                          "exchange": gather.get("mode"),
-                         "stream_bytes": gather["total"], "shard_bytes": [int(x) for x in gather["lens"].cpu().tolist()]}
+                         "stream_bytes": gather["total"], "shard_bytes": [int(x) for x in gather["lens"]]}
 
     if rank == 0:
         samples = world * B * fmt.frame_size * n_pass
@@ -609,9 +678,9 @@ def rank_main(args):
                        "segments": "one packet per segment (state = init_coefs)",
                        "rccl_ranks": dist.get_world_size() if use_dist else 0,
                        "reassembly": ("none (1 GPU)" if not use_dist else
-                                      ("skipped" if args.no_reassemble else "RCCL: all-gather of shard lengths + packet sizes, grouped "
-                                       "send/recv of shard bytes straight to their prefix-sum offsets, overlapped with the "
-                                       "next pass's encode"))},
+                                      ("skipped" if args.no_reassemble else "RCCL behind the C-ABI (alac_hip_reassemble_begin/_finish): "
+                                       "all-gather of shard lengths + packet sizes, one group of ncclSend/ncclRecv of the shard "
+                                       "bytes straight to their prefix-sum offsets, overlapped with the next pass's encode"))},
             "ms_per_encode": round(dt / n_pass * 1e3, 4),
             "packets_per_s": round(world * B * n_pass / dt, 1),
             "x_realtime": round(value * 1e6 / 44100.0, 1),
@@ -623,6 +692,11 @@ def rank_main(args):
             "calls_with_stage_events": calls,
             "roofline": roof,
         }
+        if dt_plain is not None:
+            out["value_no_reassemble"] = round(samples / dt_plain / 1e6, 3)
+            out["ms_per_encode_no_reassemble"] = round(dt_plain / n_pass * 1e3, 4)
+            out["value_note"] = ("`value` includes the RCCL re-assembly of every pass (overlapped with the next pass's encode); "
+                                 "`value_no_reassemble` is the same K steps with the exchange switched off, timed right after")
         if reasm_ms is not None:
             out["reassembly_ms"] = round(reasm_ms, 4)
             out["reassembly_note"] = ("device time per encode pass of the exchange (length all-gathers + grouped send/recv of the shard "
@@ -658,7 +732,7 @@ def rank_main(args):
                     out[name] = encode_leg(torch, alac_amd, ctx, alac_amd.make_format(4096, depth, 2, 44100), packets, every=every)
                 except Exception as e:  # a leg never takes the headline down
                     out[name] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
     return 0

@@ -264,6 +264,46 @@ int32_t alac_hip_synth_pcm(alac_hip_ctx *ctx, uint64_t first_frame, uint32_t num
 int32_t alac_hip_shard_range(uint64_t num_units, uint32_t world, uint32_t rank, uint64_t *first, uint64_t *count);
 int32_t alac_hip_shard_offsets(const uint64_t *shard_bytes, uint32_t world, uint64_t *offsets);
 
+/* ---- stream re-assembly across the GPUs of one node, on RCCL (alac_comm.cpp) ------------------
+ * BASELINE north_star: "frames are sharded across the 8 GPUs of one node with RCCL all-gather over xGMI to reassemble the
+ * stream".  No reference counterpart (the fork is single-GPU); what makes it legal is the byte alignment of every packet
+ * (codec/ALACEncoder.cu:1039).  One process per GPU, one alac_hip_comm per process; librccl is loaded on first use.
+ *   alac_hip_comm_unique_id   rank 0 makes the 128-byte ncclUniqueId and hands it to the other ranks by whatever channel
+ *                             the launcher has (a file, a socket, torch.distributed's store)
+ *   alac_hip_comm_create      ncclCommInitRank on `device`; collective over all `world` ranks.  kALAC_UnimplementedError
+ *                             if librccl cannot be loaded
+ * Re-assembly of one pass, two phases so that a pipelined caller never waits for the GPU between two encodes; `slot`
+ * (0 .. ALAC_HIP_COMM_SLOTS-1) names the pass while both are outstanding:
+ *   alac_hip_reassemble_begin   enqueues on `stream` (hipStream_t): all-gather of {shard bytes, shard capacity, output
+ *                             capacity} and — when d_packet_bytes is given — of the per-packet sizes into d_all_packet_bytes
+ *                             [world * num_packets] (equal num_packets on every rank: the CAF 'pakt' table of the whole
+ *                             stream); the table's copy to pinned host memory and an event.  d_shard_bytes: device pointer
+ *                             to this rank's byte count (d_packet_offsets + num_packets of alac_hip_encode).  No host wait.
+ *   alac_hip_reassemble_finish  waits for that event only, computes the offsets (alac_hip_shard_offsets; copied to
+ *                             h_offsets[world + 1] when non-NULL), and enqueues ONE group on `stream`: ncclRecv of every
+ *                             peer's shard straight at its offset in d_stream_out, ncclSend of d_shard to every peer, the
+ *                             own shard as a device copy.  kALAC_ParamError — on EVERY rank alike, before anything is
+ *                             posted — if a shard is longer than its buffer or the stream longer than any rank's
+ *                             out_capacity.
+ *   alac_hip_reassemble       both phases back to back (slot 0). */
+typedef struct alac_hip_comm alac_hip_comm;
+#define ALAC_HIP_COMM_ID_BYTES 128
+#define ALAC_HIP_COMM_SLOTS 4
+int32_t alac_hip_comm_unique_id(uint8_t *h_id);
+int32_t alac_hip_comm_create(alac_hip_comm **out_comm, int32_t device, const uint8_t *h_id, uint32_t rank, uint32_t world);
+void alac_hip_comm_destroy(alac_hip_comm *comm);
+uint32_t alac_hip_comm_rank(const alac_hip_comm *comm);
+uint32_t alac_hip_comm_world(const alac_hip_comm *comm);
+const char *alac_hip_comm_last_error(const alac_hip_comm *comm);
+int32_t alac_hip_reassemble_begin(alac_hip_comm *comm, uint32_t slot, const uint64_t *d_shard_bytes, uint64_t shard_capacity,
+                                  uint64_t out_capacity, const uint32_t *d_packet_bytes, uint32_t num_packets,
+                                  uint32_t *d_all_packet_bytes, void *stream);
+int32_t alac_hip_reassemble_finish(alac_hip_comm *comm, uint32_t slot, const uint8_t *d_shard, uint8_t *d_stream_out,
+                                   uint64_t *h_offsets, void *stream);
+int32_t alac_hip_reassemble(alac_hip_comm *comm, const uint8_t *d_shard, const uint64_t *d_shard_bytes, uint64_t shard_capacity,
+                            const uint32_t *d_packet_bytes, uint32_t num_packets, uint32_t *d_all_packet_bytes,
+                            uint8_t *d_stream_out, uint64_t out_capacity, uint64_t *h_offsets, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1176,7 +1176,9 @@ int32_t oalac_decode_packet(oalac_decoder *d, const uint8_t *packet, uint32_t pk
             /* gpu_copyPredictorTo16/20/24/24Shift/32/32Shift, ALACDecoder.cu:385-495 */
             for (uint32_t i = 0; i < numSamples; i++) {
                 int32_t val = d->mixU[i];
-                if (bytesShifted) val = (int32_t)(((uint32_t)val << (bytesShifted * 8)) | d->shiftBuf[i]);
+                /* only gpu_copyPredictorTo24Shift / To32Shift re-attach the shifted-off bytes (fillWriteBuffer :503-531);
+                 * the 16- and 20-bit routines write the predictor value as it is */
+                if (bytesShifted && d->bitDepth >= 24) val = (int32_t)(((uint32_t)val << (bytesShifted * 8)) | d->shiftBuf[i]);
                 store_sample(pcmOut + ((size_t)i * numChannels + channelIndex) * bps, d->bitDepth, val);
             }
             channelIndex += 1;

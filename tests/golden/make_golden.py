@@ -12,6 +12,9 @@ Outputs (data only — inputs and expected outputs, no reference source):
                       pc_block/dyn_comp, chained and independent
   known_answers.json  sizes / FNV-1a-64 of whole-file encodes of the three reference WAVs and of the
                       synthetic workload (pins the generator too)
+  forged.npz          packets with FOREIGN header / cookie parameters (oracle/forge.py run over the reference's compiled
+                      pc_block / dyn_comp / BitBufferWrite) and the PCM the decoder driver produces from them over the
+                      reference's dyn_decomp / unpc_block: the pin of the decoder's general paths
   caf_headers.json    chunk bytes, BER codes and base packet tables from the reference's own CAFFileALAC.cpp
   wav50_pcm.xz,       the sample data of the reference's audio/50.wav (stereo, 237 packets) and audio/05.wav (mono, 302
   wav05_pcm.xz        packets), xz-compressed: the INPUTS of the whole-file known answers, so that the GPU box (which has
@@ -129,6 +132,41 @@ def make_packets(o, r):
     print("packets.npz written")
 
 
+FORGED_STREAMS = [  # (depth, channels, frame size, cookie pb, mb, kb, packets)
+    (16, 2, 256, 40, 10, 14, 40), (16, 2, 256, 20, 5, 9, 24), (16, 1, 256, 63, 30, 16, 24), (24, 2, 128, 40, 10, 14, 24),
+    (24, 1, 128, 30, 12, 11, 16), (20, 2, 128, 40, 10, 14, 16), (20, 1, 96, 50, 8, 13, 12), (32, 2, 64, 40, 10, 14, 16),
+    (32, 1, 64, 25, 10, 12, 12),
+]
+
+
+def make_forged(o, r):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import forge
+    fr = forge.Forger(o, dict(pc_block=r.lib.pc_block, dyn_comp=r.lib.ref_dyn_comp_flat, put_bits=r.lib.ref_put_bits))
+    out, meta = {}, []
+    for si, (depth, ch, frame, pb, mb, kb, count) in enumerate(FORGED_STREAMS):
+        rng = np.random.default_rng(4000 + si)
+        pk, pcm, ok = forge.forge_batch(fr, rng, count, depth, ch, frame, pb, mb, kb)
+        ck = forge.cookie(frame, depth, ch, pb, mb, kb)
+        dec = o.decoder(ck, hooks=r.hooks())
+        bpf = ch * forge.BPS[depth]
+        want = []
+        for a, p, k in zip(pk, pcm, ok):
+            st, w, n = dec.decode_packet(a, bpf)
+            assert st == 0 and n * bpf == len(p)
+            assert (not k) or np.array_equal(w, p)
+            want.append(w)
+        out[f"s{si}_stream"] = np.concatenate(pk)
+        out[f"s{si}_sizes"] = np.array([len(a) for a in pk], np.uint32)
+        out[f"s{si}_pcm"] = np.concatenate(want)
+        out[f"s{si}_cookie"] = ck
+        meta.append(dict(id=si, depth=depth, channels=ch, frame=frame, pb=pb, mb=mb, kb=kb, packets=count,
+                         lossless=[bool(k) for k in ok]))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "forged.npz"), **out)
+    print("forged.npz:", sum(m["packets"] for m in meta), "packets,", os.path.getsize(os.path.join(HERE, "forged.npz")), "bytes")
+
+
 def make_wav_pcm_fixtures():
     import lzma
     for name, out in (("50.wav", "wav50_pcm.xz"), ("05.wav", "wav05_pcm.xz")):
@@ -184,5 +222,6 @@ if __name__ == "__main__":
     make_stage_vectors(o, r)
     make_packets(o, r)
     make_known_answers(o, r)
+    make_forged(o, r)
     make_wav_pcm_fixtures()
     make_caf_headers()

@@ -75,3 +75,52 @@ def test_segment_bound_instead_of_read_back(gpu_ctx, oracle):
     assert ei.value.code == -50 and "max_segment_packets" in str(ei.value)
     s, z = gpu_ctx.encode_to_host(fmt, d, n, seg_first=sf, max_segment_packets=5)  # the error is consumed
     assert np.array_equal(s, ref)
+
+
+@pytest.mark.parametrize("variant", ["default", "lane", "unfolded"])
+@pytest.mark.parametrize("table", ["too_long", "past_the_batch", "descending", "bound_too_small_big_batch"])
+def test_refused_segment_table_touches_nothing(table, variant):
+    """a segment table that contradicts the caller's bound is only DISCOVERED on the device, with every later launch
+    already enqueued behind the check.  Fresh context, workspace / size / offset / output buffers poisoned: the call must fail
+    with kALAC_ParamError at the synchronize and must not have written one byte of packet data (no index formed from a bad
+    entry, nothing packed from stale records)."""
+    import torch
+    from alac_amd.capi import AlacError
+    ctx = alac_amd.Context(0)
+    if variant == "lane":
+        ctx.set_option("encoder_lane", 1)
+    elif variant == "unfolded":
+        ctx.set_option("fold", 0)
+    fmt = alac_amd.make_format(256, 16, 2)
+    if table == "too_long":
+        seg_first, n, bound = [0, 3, 4, 9, 12], 12, 4
+    elif table == "past_the_batch":
+        seg_first, n, bound = [0, 3, 4, 0x7fffff00, 12], 12, 5
+    elif table == "descending":
+        seg_first, n, bound = [0, 9, 4, 3, 12], 12, 12
+    else:
+        n, bound = 3000, 2
+        seg_first = list(range(0, n - 200, 2)) + [n]  # the last segment has 202 packets
+    d = ctx.synth_pcm(3, n, fmt)
+    sf = torch.tensor(seg_first, dtype=torch.int32).cuda()
+    nseg = len(seg_first) - 1
+    wsb = int(ctx.lib.alac_hip_encode_workspace_bytes(fmt, n, nseg))
+    ctx._ws = torch.full((wsb,), 0xA5, dtype=torch.uint8, device="cuda")
+    bufs = ctx.encode_buffers(fmt, n)
+    bufs["out"].fill_(0x5A)
+    bufs["sizes"].fill_(0x7fff0000)
+    bufs["offsets"].fill_(0x7fff000000000000)
+    torch.cuda.synchronize()
+    ctx.encode(fmt, d, n, seg_first=sf, bufs=bufs, max_segment_packets=bound)
+    with pytest.raises(AlacError) as ei:
+        ctx.synchronize()
+    assert ei.value.code == -50
+    torch.cuda.synchronize()
+    assert bool((bufs["out"] == 0x5A).all()), "packet bytes were written from an unvalidated table"
+    assert int(bufs["offsets"][-1].item()) == 0
+    # and the context is usable afterwards
+    good = torch.arange(0, n + 1, dtype=torch.int32).cuda()
+    s, z = ctx.encode_to_host(fmt, d, n, seg_first=good, max_segment_packets=1)
+    s2, z2 = ctx.encode_to_host(fmt, d, n)
+    assert np.array_equal(s, s2) and np.array_equal(z, z2)
+    ctx.close()

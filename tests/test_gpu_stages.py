@@ -87,3 +87,32 @@ def test_pc_block_any_tap_count_matches_oracle(gpu_ctx, oracle, na):
             want_pc, want_co = oracle.pc_block(x[r], num, co0[r], na, chanbits)
             assert np.array_equal(pc[r, :num].cpu().numpy(), want_pc[:num]), (na, chanbits, num, r)
             assert np.array_equal(co[r, :na].cpu().numpy(), want_co[:na]), (na, chanbits, num, r)
+
+
+@pytest.mark.parametrize("chanbits", [24, 25, 32])
+def test_wide_full_scale_samples_wrap_like_the_reference(gpu_ctx, oracle, chanbits):
+    """full-scale material at chanBits 24 / 25 (24-bit coded without shift-off bytes) and 32 (32-bit mono): differences of
+    two samples overflow int32 at 32 bits and the reference's compiled objects wrap (pinned in tests/test_oracle.py); every
+    tap count class and denominator shift other than 9 (the stage entry points take the header's fields)"""
+    import torch
+    rng = np.random.default_rng(chanbits)
+    lim = (1 << (chanbits - 1)) - 1
+    for na, ds in ((4, 9), (8, 9), (8, 5), (4, 12), (1, 12), (6, 5), (16, 7), (30, 4), (31, 9), (0, 9), (2, 1), (12, 15)):
+        rows, num = 4, 200
+        x = rng.integers(-lim - 1, lim + 1, size=(rows, num + 40)).astype(np.int32)
+        x[1] //= 3
+        co0 = rng.integers(-(1 << ds), (1 << ds) + 1, size=(rows, 32)).clip(-32768, 32767).astype(np.int16)
+        co = torch.from_numpy(co0.copy()).cuda()
+        pc = gpu_ctx.pc_block(torch.from_numpy(x).cuda(), num, co, na, chanbits, denshift=ds)
+        gpu_ctx.synchronize()
+        co2 = torch.from_numpy(co0.copy()).cuda()
+        back = gpu_ctx.pc_block(pc, num, co2, na, chanbits, denshift=ds, decode=True)
+        gpu_ctx.synchronize()
+        for r in range(rows):
+            want_pc, want_co = oracle.pc_block(x[r], num, co0[r], na, chanbits, ds)
+            assert np.array_equal(pc[r, :num].cpu().numpy(), want_pc[:num]), (na, ds, r)
+            want_x, want_co2 = oracle.unpc_block(want_pc, num, co0[r], na, chanbits, ds)
+            assert np.array_equal(back[r, :num].cpu().numpy(), want_x[:num]), (na, ds, r)
+            if na not in (0, 31):
+                assert np.array_equal(co[r, :na].cpu().numpy(), want_co[:na]), (na, ds, r)
+                assert np.array_equal(co2[r, :na].cpu().numpy(), want_co2[:na]), (na, ds, r)

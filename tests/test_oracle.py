@@ -103,6 +103,46 @@ def test_stages_match_reference_objects_randomized(oracle, ref):
         assert st == 0 and n3 == n1 and np.array_equal(back, pc)
 
 
+def test_stages_match_reference_objects_at_foreign_parameters(oracle, ref):
+    """the pin of the DECODER's general paths: `pc_block` / `unpc_block` at denshift != 9 (header field, codec/ALACDecoder.cu:
+    800-801) with every tap count 0..31, and `dyn_comp` / `dyn_decomp` at other (mb, pb, kb) — cookie fields and
+    pb = (cookie.pb * pbFactor) / 4 (:825, :841) — oracle == the reference's compiled objects"""
+    rng = np.random.default_rng(20261005)
+    for trial in range(400):
+        na = int(rng.integers(0, 32))
+        cb = int(rng.choice([9, 16, 17, 20, 21, 24, 25]))
+        ds = int(rng.integers(1, 16))
+        num = int(rng.choice([1, 2, 5, 12, 33, 128, 400]))
+        amp = int(rng.choice([3, 500, 30000, 1 << (cb - 1)]))
+        amp = min(amp, 1 << (cb - 1))
+        x = rng.integers(-amp, amp, size=max(num, 40) + 8).astype(np.int32)
+        scale = int(rng.choice([1 << ds, 2000, 32767]))
+        co = rng.integers(-scale, scale + 1, size=32).clip(-32768, 32767).astype(np.int16)
+        a, ca = oracle.pc_block(x, num, co, na, cb, ds)
+        b, cb2 = oracle.pc_block(x, num, co, na, cb, ds, fn=ref.lib.pc_block)
+        assert np.array_equal(a[:num], b[:num]) and np.array_equal(ca, cb2), (na, cb, ds, num)
+        y, cy = oracle.unpc_block(a, num, co, na, cb, ds)
+        y2, cy2 = oracle.unpc_block(a, num, co, na, cb, ds, fn=ref.lib.unpc_block)
+        assert np.array_equal(y[:num], y2[:num]) and np.array_equal(cy, cy2), (na, cb, ds, num)
+        bs = int(rng.choice([8, 9, 16, 17, 20, 21, 24, 25, 32]))
+        n = int(rng.choice([1, 7, 128, 512]))
+        pbf = int(rng.integers(0, 8))
+        cpb, mb, kb = int(rng.choice([1, 20, 40, 63, 255])), int(rng.choice([1, 5, 10, 30, 255])), int(rng.integers(1, 17))
+        pb = (cpb * pbf) // 4
+        lim = (1 << (bs - 1)) - 1
+        pc = np.clip((rng.standard_normal(n) * rng.choice([0.3, 2, 300, lim])).astype(np.int64), -lim, lim).astype(np.int32)
+        if trial % 5 == 0:
+            pc[rng.random(n) < 0.9] = 0  # long zero runs
+        d1, n1 = oracle.dyn_comp(pc, bs, start_bit=trial % 8, mb0=mb, pb=pb, kb=kb)
+        d2, n2 = oracle.dyn_comp(pc, bs, start_bit=trial % 8, mb0=mb, pb=pb, kb=kb, fn=ref.lib.ref_dyn_comp_flat)
+        assert n1 == n2 and np.array_equal(d1, d2), (bs, n, mb, pb, kb)
+        st, back, n3 = oracle.dyn_decomp(d1, len(d1), n, bs, start_bit=trial % 8, mb0=mb, pb=pb, kb=kb)
+        st2, back2, n4 = oracle.dyn_decomp(d1, len(d1), n, bs, start_bit=trial % 8, mb0=mb, pb=pb, kb=kb,
+                                           fn=ref.lib.ref_dyn_decomp_flat)
+        assert st == st2 == 0 and n3 == n4 == n1, (bs, n, mb, pb, kb)
+        assert np.array_equal(back, back2) and np.array_equal(back, pc), (bs, n, mb, pb, kb)
+
+
 def test_bit_writer_matches_reference(oracle, ref):
     import ctypes as C
     rng = np.random.default_rng(3)
