@@ -52,53 +52,43 @@ AlacOptions alac_options_from_env()
 {
     AlacOptions o;
     o.thru = env_int("ALAC_HIP_THRU", o.thru);
-    o.idleFast = env_int("ALAC_HIP_IDLEFAST", o.idleFast);
-    o.wide81 = env_int("ALAC_HIP_WIDE81", o.wide81);
     o.narrow = env_int("ALAC_HIP_NARROW", o.narrow);
     o.splitCoder = env_int("ALAC_HIP_SPLIT_CODER", o.splitCoder) != 0;
-    o.pubFence = env_int("ALAC_HIP_PUBFENCE", o.pubFence) != 0;
     o.overlapPos = env_int("ALAC_HIP_OVERLAP_POS", o.overlapPos) != 0;
     o.fused = env_int("ALAC_HIP_FUSED", o.fused) != 0;
-    o.subBatch = env_int("ALAC_HIP_SUBBATCH", o.subBatch);
+    o.fold = env_int("ALAC_HIP_FOLD", o.fold) != 0;
     if (const char *e = getenv("ALAC_HIP_ENCODER")) o.laneEncoder = strcmp(e, "lane") == 0;
     if (const char *e = getenv("ALAC_HIP_DECODER")) o.laneDecoder = strcmp(e, "lane") == 0;
     if (const char *e = getenv("ALAC_HIP_DEC_FUSED")) o.decFused = *e ? (e[0] == '0' ? 0 : 1) : -1;
-    o.decWide = env_int("ALAC_HIP_DEC_WIDE", o.decWide) != 0;
     o.decPair = env_int("ALAC_HIP_DEC_PAIR", o.decPair) != 0;
-    o.decLocal = env_int("ALAC_HIP_DEC_LOCAL", o.decLocal) != 0;
-    o.decPubMask = env_int("ALAC_HIP_DEC_PUBMASK", o.decPubMask);
     o.stageTaps = env_int("ALAC_HIP_STAGE_TAPS", o.stageTaps) != 0;
     o.loseHandoff = env_int("ALAC_HIP_DEBUG_LOSE_HANDOFF", o.loseHandoff) == 1;
-    o.persist = env_int("ALAC_HIP_PERSIST", o.persist);
-    o.classFused = env_int("ALAC_HIP_CLASS_FUSED", o.classFused) != 0;
-    o.searchFused = env_int("ALAC_HIP_SEARCH_FUSED", o.searchFused) != 0;
-    o.fold = env_int("ALAC_HIP_FOLD", o.fold);
-    o.thruWg4 = env_int("ALAC_HIP_THRU_WG4", o.thruWg4);
-    o.ldsPad = env_int("ALAC_HIP_LDS_PAD", o.ldsPad);
-    o.countWalk = env_int("ALAC_HIP_COUNT_WALK", o.countWalk);
-    o.initState = env_int("ALAC_HIP_INIT_STATE", o.initState) != 0;
     return o;
 }
 
-int32_t *alac_option_slot(AlacOptions &o, const char *key)
+// key -> slot and the range alac_hip_set_option accepts (include/alac_hip.h documents exactly these)
+const AlacOptionKey *alac_option_keys(uint32_t *count)
+{
+    static const AlacOptionKey table[] = {
+        {"thru", &AlacOptions::thru, -1, 1},           {"narrow", &AlacOptions::narrow, -1, 1},
+        {"split_coder", &AlacOptions::splitCoder, 0, 1}, {"overlap_pos", &AlacOptions::overlapPos, 0, 1},
+        {"fused", &AlacOptions::fused, 0, 1},          {"fold", &AlacOptions::fold, 0, 1},
+        {"fast_mode", &AlacOptions::fastMode, 0, 1},   {"encoder_lane", &AlacOptions::laneEncoder, 0, 1},
+        {"decoder_lane", &AlacOptions::laneDecoder, 0, 1}, {"dec_fused", &AlacOptions::decFused, -1, 1},
+        {"dec_pair", &AlacOptions::decPair, 0, 1},     {"stage_taps", &AlacOptions::stageTaps, 0, 1},
+        {"debug_lose_handoff", &AlacOptions::loseHandoff, 0, 1}, {"debug_waves", &AlacOptions::debugWaves, 0, 1},
+    };
+    if (count) *count = (uint32_t)(sizeof(table) / sizeof(table[0]));
+    return table;
+}
+
+const AlacOptionKey *alac_option_find(const char *key)
 {
     if (!key) return nullptr;
-    static const struct { const char *name; int32_t AlacOptions::*slot; } table[] = {
-        {"thru", &AlacOptions::thru},           {"idlefast", &AlacOptions::idleFast},
-        {"wide81", &AlacOptions::wide81},       {"narrow", &AlacOptions::narrow},
-        {"split_coder", &AlacOptions::splitCoder}, {"pubfence", &AlacOptions::pubFence},
-        {"overlap_pos", &AlacOptions::overlapPos}, {"fused", &AlacOptions::fused},
-        {"subbatch", &AlacOptions::subBatch},   {"encoder_lane", &AlacOptions::laneEncoder},
-        {"decoder_lane", &AlacOptions::laneDecoder}, {"dec_fused", &AlacOptions::decFused},
-        {"dec_wide", &AlacOptions::decWide},    {"dec_pubmask", &AlacOptions::decPubMask}, {"dec_pair", &AlacOptions::decPair}, {"dec_local", &AlacOptions::decLocal},
-        {"stage_taps", &AlacOptions::stageTaps}, {"debug_lose_handoff", &AlacOptions::loseHandoff},
-        {"persist", &AlacOptions::persist},     {"class_fused", &AlacOptions::classFused},
-        {"search_fused", &AlacOptions::searchFused}, {"fold", &AlacOptions::fold}, {"thru_wg4", &AlacOptions::thruWg4}, {"fast_mode", &AlacOptions::fastMode}, {"lds_pad", &AlacOptions::ldsPad},
-        {"debug_waves", &AlacOptions::debugWaves}, {"count_walk", &AlacOptions::countWalk},
-        {"init_state", &AlacOptions::initState},
-    };
-    for (const auto &t : table)
-        if (strcmp(t.name, key) == 0) return &(o.*(t.slot));
+    uint32_t n = 0;
+    const AlacOptionKey *t = alac_option_keys(&n);
+    for (uint32_t i = 0; i < n; i++)
+        if (strcmp(t[i].name, key) == 0) return t + i;
     return nullptr;
 }
 
@@ -213,7 +203,7 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.resB = off;
     off = align_up(off + n8 * 2 * lanes * 4, 256);
     // final residuals: columns handed out per packet class (k_class_assign), two regions padded to 64 -> up to 128 spare
-    L.colsPad = (uint32_t)lanes + 256 * kMaxSubBatches;  // every overlapped sub-batch rounds up to whole waves and pads its two regions
+    L.colsPad = (uint32_t)lanes + 256;  // the two class regions of the final pass are padded to whole waves
     L.resC = off;
     off = align_up(off + ((uint64_t)f->frame_size + 16) * L.colsPad * 4, 256);
     L.bits1 = off;
@@ -228,7 +218,7 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     L.rowReady = off;
     off = align_up(off + lanes * 4, 256);
     L.cls = off;  // ClassInfo + per-1024-packet class counts of the compaction
-    off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2 * kMaxSubBatches) * 8, 256);
+    off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2) * 8, 256);
     L.colChain = off;
     off = align_up(off + (uint64_t)L.colsPad * 4, 256);
     // Tiny batches (<= 4096 chains: a chained file, a few hundred files side by side; the four-lanes-per-chain regime of
@@ -248,15 +238,6 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
 
 // option "encoder_lane" selects the fused lane-per-chain kernel (alac_encode.hip); default is the
 // tap-parallel pipeline (alac_encode_v1.hip).  Both are HIP paths; there is no CPU path.
-// option "subbatch" = n (1..8) overrides the number of overlapped sub-batches of the tap-parallel pipeline
-uint32_t sub_batches_requested(const alac_hip_ctx *ctx)
-{
-    int n = ctx->opt.subBatch;  // 0 = default (v1_sub_batches: one; measured, no gain from more in either regime)
-    if (n < 0) n = 0;
-    if (n > (int)kMaxSubBatches) n = kMaxSubBatches;
-    return (uint32_t)n;
-}
-
 bool use_lane_encoder(const alac_hip_ctx *ctx) { return ctx->opt.laneEncoder != 0; }
 
 // > 2 channels: the mono / stereo pipeline once per element over a gathered copy of its channels, then the splice
@@ -429,9 +410,9 @@ void alac_hip_destroy(alac_hip_ctx *ctx)
     ctx->events.clear();
     if (ctx->vsReady) {
         (void)hipSetDevice(ctx->device);
-        for (uint32_t i = 0; i + 1 < kMaxSubBatches; i++) {
-            (void)hipStreamSynchronize(ctx->vs.side[i]);
-            (void)hipStreamDestroy(ctx->vs.side[i]);
+        (void)hipStreamSynchronize(ctx->vs.side[0]);
+        (void)hipStreamDestroy(ctx->vs.side[0]);
+        for (uint32_t i = 0; i < kSideEvents; i++) {
             (void)hipEventDestroy(ctx->vs.stagger[i]);
             (void)hipEventDestroy(ctx->vs.join[i]);
         }
@@ -464,18 +445,19 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx)
 int32_t alac_hip_set_option(alac_hip_ctx *ctx, const char *key, int32_t value)
 {
     if (!ctx) return ALAC_HIP_ParamError;
-    int32_t *slot = alac_option_slot(ctx->opt, key);
-    if (!slot) return fail(ctx, ALAC_HIP_ParamError, "unknown option");
-    *slot = value;
+    const AlacOptionKey *k = alac_option_find(key);
+    if (!k) return fail(ctx, ALAC_HIP_ParamError, "unknown option");
+    if (value < k->lo || value > k->hi) return fail(ctx, ALAC_HIP_ParamError, "option value outside its documented range");
+    ctx->opt.*(k->slot) = value;
     return ALAC_HIP_noErr;
 }
 
 int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value)
 {
     if (!ctx || !value) return ALAC_HIP_ParamError;
-    const int32_t *slot = alac_option_slot(ctx->opt, key);
-    if (!slot) return fail(ctx, ALAC_HIP_ParamError, "unknown option");
-    *value = *slot;
+    const AlacOptionKey *k = alac_option_find(key);
+    if (!k) return fail(ctx, ALAC_HIP_ParamError, "unknown option");
+    *value = ctx->opt.*(k->slot);
     return ALAC_HIP_noErr;
 }
 
@@ -492,8 +474,10 @@ const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt
     const uint32_t ch = fmt->num_channels > 2 ? 2 : fmt->num_channels;
     if (v1_throughput_regime(num_segments, ch, ctx->opt)) return "throughput";
     const uint64_t chains = (uint64_t)num_segments * ch;
+    // the launcher's own predicates (launch_encode_v1 / launch_v1_typed): fuse = fused && !thru, narrow = narrow && fuse
+    if (!ctx->opt.fused) return "stagewise";
     const bool narrow = ctx->opt.narrow >= 0 ? ctx->opt.narrow != 0 : chains <= 4096;
-    return (narrow && ctx->opt.fused) ? "tiny" : "latency";
+    return narrow ? "tiny" : "latency";
 }
 
 const char *alac_hip_last_error(const alac_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -585,7 +569,7 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
     // the stereo batch runs on the context's stream, the mono batch beside it on a second stream (both are bound by
     // the latency of one wave, not by the machine)
     const bool both = M.g[0].count && M.g[1].count;
-    bool side = both && sub_batches_requested(ctx) <= 1;
+    bool side = both;
     if (side && !ensure_second_stream(ctx)) return fail(ctx, ALAC_HIP_MemFullError, "creating the second stream");
     if (side) {
         (void)hipEventRecord(ctx->mcFork, mainStream);
@@ -593,6 +577,15 @@ static int32_t encode_elements(alac_hip_ctx *ctx, const alac_hip_format *fmt, co
     }
     int32_t rc = ALAC_HIP_noErr;
     hipError_t copyErr = hipSuccess;
+    // SetFastMode is consulted for 2-channel STREAMS only (codec/ALACEncoder.cu:998-1001): the stereo elements of a
+    // > 2-channel stream are searched like everything else
+    const int32_t fastModeOfCtx = ctx->opt.fastMode;
+    ctx->opt.fastMode = 0;
+    struct Restore {
+        alac_hip_ctx *c;
+        int32_t v;
+        ~Restore() { c->opt.fastMode = v; }
+    } restoreFast{ctx, fastModeOfCtx};
     for (int gi = 0; gi < 2 && rc == ALAC_HIP_noErr; gi++) {
         const McGroup &G = M.g[gi];
         if (!G.count) continue;
@@ -696,7 +689,7 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
     pa.offsets = d_packet_offsets;
     pa.out = d_out;
     pa.segBad = ea.segBad;
-    constexpr uint32_t EV = (kMaxSubBatches + 1) * (kNumStages + 1);
+    constexpr uint32_t EV = kEventBlocks * (kNumStages + 1);
     hipEvent_t *ev = nullptr;
     if (timed && ctx->profile && (uint64_t)(ctx->profCalls + 1) * EV <= ctx->events.size())
         ev = &ctx->events[ctx->profCalls++ * EV];
@@ -708,20 +701,18 @@ static int32_t encode_core(alac_hip_ctx *ctx, const alac_hip_format *fmt, const 
     if (use_lane_encoder(ctx)) {
         if (ev) ctx->profSub.push_back(0);
         e = launch_encode(fmt->bit_depth, fmt->num_channels, ea, pa, num_packets, ctx->stream,
-                          ev ? ev + kMaxSubBatches * (kNumStages + 1) : nullptr);
+                          ev ? ev + (kNumStages + 1) : nullptr);
     } else {
         if (!ctx->vsReady) {
-            ctx->vs.maxSub = kMaxSubBatches;
-            bool ok = hipEventCreateWithFlags(&ctx->vs.fork, hipEventDisableTiming) == hipSuccess;
-            for (uint32_t i = 0; ok && i + 1 < kMaxSubBatches; i++)
-                ok = hipStreamCreateWithFlags(&ctx->vs.side[i], hipStreamNonBlocking) == hipSuccess &&
-                     hipEventCreateWithFlags(&ctx->vs.stagger[i], hipEventDisableTiming) == hipSuccess &&
+            bool ok = hipEventCreateWithFlags(&ctx->vs.fork, hipEventDisableTiming) == hipSuccess &&
+                      hipStreamCreateWithFlags(&ctx->vs.side[0], hipStreamNonBlocking) == hipSuccess;
+            for (uint32_t i = 0; ok && i < kSideEvents; i++)
+                ok = hipEventCreateWithFlags(&ctx->vs.stagger[i], hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&ctx->vs.join[i], hipEventDisableTiming) == hipSuccess;
             if (!ok) return fail(ctx, ALAC_HIP_MemFullError, "creating side streams");
             ctx->vsReady = true;
         }
-        ctx->vs.numSub = sub_batches_requested(ctx);
-        if (ev) ctx->profSub.push_back(v1_sub_batches(num_segments, ctx->vs.numSub, fmt->num_channels));
+        if (ev) ctx->profSub.push_back(1);
         // packets per segment: the pipeline runs once per packet position (a chained segment is serial)
         uint32_t maxSeg = 1;
         if (d_seg_first && maxSegHint) {
@@ -779,7 +770,7 @@ int32_t alac_hip_profile_begin(alac_hip_ctx *ctx, uint32_t max_calls)
 {
     if (!ctx) return ALAC_HIP_ParamError;
     if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipSetDevice");
-    while (ctx->events.size() < (size_t)max_calls * (kMaxSubBatches + 1) * (kNumStages + 1)) {
+    while (ctx->events.size() < (size_t)max_calls * kEventBlocks * (kNumStages + 1)) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return fail(ctx, ALAC_HIP_MemFullError, "hipEventCreate");
         ctx->events.push_back(e);
@@ -797,7 +788,7 @@ int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, ALAC_HIP_ParamError, "hipStreamSynchronize", e);
     constexpr uint32_t BLK = kNumStages + 1;
-    constexpr uint32_t EV = (kMaxSubBatches + 1) * BLK;
+    constexpr uint32_t EV = kEventBlocks * BLK;
     double t[kNumStages] = {0};
     double launches[kNumStages] = {0};
     auto elapsed = [&](hipEvent_t a, hipEvent_t b, double &acc) -> bool {
@@ -815,7 +806,7 @@ int32_t alac_hip_profile_end(alac_hip_ctx *ctx, uint32_t *out_calls, float *out_
                     return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime");
                 launches[k] += 1;
             }
-        hipEvent_t *tail = base + kMaxSubBatches * BLK;
+        hipEvent_t *tail = base + BLK;
         for (uint32_t k = (H ? kStageScan : 0); k < kNumStages; k++) {
             if (!elapsed(tail[k], tail[k + 1], t[k])) return fail(ctx, ALAC_HIP_ParamError, "hipEventElapsedTime");
             launches[k] += 1;
@@ -963,10 +954,7 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.statusOut = d_status;
     da.ho = handoff_ctl(ctx);
     da.optFused = ctx->opt.decFused;
-    da.optWide = ctx->opt.decWide;
     da.optPair = ctx->opt.decPair;
-    da.optLocal = ctx->opt.decLocal;
-    da.optPubMask = (uint32_t)ctx->opt.decPubMask;
     hipError_t e;
     if (use_lane_decoder(ctx)) {
         e = launch_decode(da, ctx->stream);

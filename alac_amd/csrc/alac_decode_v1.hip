@@ -775,13 +775,7 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
     if (coded && V.elemBit && E.status == 0) V.elemBit[p] = E.endPos;
 }
 
-__global__ __launch_bounds__(64) void k_dec_entropy(DecV1Args V)
-{
-    __shared__ uint32_t ring[64 * kWinStride];
-    entropy_body<false>(V, ring, blockIdx.x);
-}
-
-// the same with deferred residual stores (what the separate launches of a large batch use; ALAC_HIP_DEC_WIDE=0: the above)
+// separate launches of a large batch: deferred residual stores (a round's sixteen residuals leave as four 16-byte stores)
 // Four waves to a workgroup: a CU then takes the entropy waves four at a time, one per SIMD.  As single-wave workgroups
 // (about 7.6 per CU at 125 000 packets) some SIMD of a CU ended up with three of them, and the launch is as slow as that SIMD.
 constexpr int kEntWavesPerWg = 4;
@@ -966,7 +960,6 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
     }
 }
 
-__global__ __launch_bounds__(64) void k_dec_unpc_fast(DecV1Args V) { unpc_fast_body<false>(V, blockIdx.x); }
 
 // ---- separate launches (large batches): ONE lane per chain, chains sorted by tap count -------------------------------
 // Where every kernel fills the machine by itself the cost of the predictor is wave-instructions per chain step, and
@@ -1296,39 +1289,13 @@ __global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_unpc_wide(DecV1Args
     unpc_wide_body<4>(V, b, c4);
 }
 
-// ---- fused launch: a launch of WORKERS (waves), four to a workgroup with consecutive worker ids, so that the waves of a
-// workgroup get a SIMD each by construction (as single-wave workgroups their SIMD was up to whatever state the launches
-// before had left in the CU's wave allocator: see alac_encode_v1_impl.hpp, worker_id).  The entropy waves are the launch's
-// serial chain (8192 symbols per lane): roles are dealt E U .. U with R = unpcPerEnt predictor waves behind every entropy
-// wave (4 for stereo: 64 packets = 128 chains = 4 x 32), so a workgroup holds at most ONE entropy wave and, while the
-// launch has no more workgroups than the chip has CUs, a CU as well.  Nothing depends on the placement: followers wait on
-// progress words in HBM, bounded.  Behind those roles, one wave per packet for the uncompressed elements (nobody waits for
-// them; their dispatch hides under the entropy chain instead of costing a launch of its own).
-constexpr int kDecWavesPerWg = 4;
-__global__ __launch_bounds__(64 * kDecWavesPerWg, 1) void k_dec_fused(DecV1Args V, uint32_t nEnt, uint32_t nUnpc, uint32_t unpcPerEnt)
-{
-    __shared__ uint32_t ringAll[kDecWavesPerWg][64 * kWinStride];
-    const uint32_t slot = threadIdx.x >> 6, wid = blockIdx.x * (uint32_t)kDecWavesPerWg + slot;
-    const uint32_t period = unpcPerEnt + 1, paired = nEnt * period;
-    if (wid < paired) {
-        const uint32_t t = wid / period, r = wid % period;
-        if (r == 0) {
-            entropy_body<true>(V, ringAll[slot], t);
-        } else {
-            const uint32_t b = t * unpcPerEnt + (r - 1);
-            if (b < nUnpc) unpc_fast_body<true>(V, b);
-        }
-    } else if (wid - paired < V.d.numPackets) {
-        raw_body(V, wid - paired, threadIdx.x & 63, 64);
-    }
-}
-
-// ---- fused launch, round 3 form: the followers of an entropy wave are waves of ITS workgroup.  A workgroup = the entropy
+// ---- fused launch: the followers of an entropy wave are waves of ITS workgroup.  A workgroup = the entropy
 // wave of kFusedPpw = 48 packets + the three predictor waves of their 96 chains (first-channel chains, then second-channel
 // chains, 32 to a wave), one wave per SIMD of one CU.  Producer and followers share that CU's L1 and L2, so a publish is a
-// workgroup-scope release (wait for the stores to leave the wave) and two LDS words per packet — in the form above it is an
-// agent-scope release, i.e. an L2 write-back of ~10 us, sixteen times per packet.  Workgroups >= nEnt: one wave per packet
-// for the uncompressed elements, as above.
+// workgroup-scope release (wait for the stores to leave the wave) and two LDS words per packet.  (Rounds 2-3 had the
+// followers anywhere on the chip behind progress words in HBM: every publish was an agent-scope release — an L2 write-back of
+// ~10 us, sixteen times per packet; removed in round 4.)  Workgroups >= nEnt: one wave per packet for the uncompressed
+// elements (nobody waits for them; their dispatch hides under the entropy chain instead of costing a launch of its own).
 constexpr int kFusedPpw = 48;
 __global__ __launch_bounds__(256, 1) void k_dec_fused_wg(DecV1Args V, uint32_t nEnt)
 {
@@ -1589,12 +1556,12 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     // fill it saves: 10 000 packets 1.95 -> 2.14 ms):
     // every sample a later kernel reads is then written by somebody (coded rows: residuals + run zeros; uncompressed rows:
     // k_dec_raw; absent elements of a > 2-channel round: k_dec_unmix reads nothing), and the fill is left out
-    const bool zerosWritten = !fused0 && V.d.optWide != 0;
+    const bool zerosWritten = !fused0;
     if (!zerosWritten) (void)hipMemsetAsync(V.plane, 0, planeBytes, sc);
     if (useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, sc);
     if (V.mismatch) (void)hipMemsetAsync(V.mismatch, 0, 4, st);
     V.lists = fused0 ? 0u : 1u;
-    V.pairs = (!fused0 && V.d.optWide != 0 && V.d.optPair != 0) ? 1u : 0u;
+    V.pairs = (!fused0 && V.d.optPair != 0) ? 1u : 0u;
     if (V.lists) (void)hipMemsetAsync(dec_lists(V).cnt, 0, kDecCounters * 4, st);
     if (stageFirst)
         hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
@@ -1605,7 +1572,7 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
         (void)hipStreamWaitEvent(st, side->join, 0);
     }
     const uint64_t lanes = (uint64_t)da.numPackets * da.numChannels;
-    const uint32_t nEnt = (da.numPackets + 63) / 64, nUnpc = (uint32_t)((lanes + 31) / 32);
+    const uint32_t nEnt = (da.numPackets + 63) / 64;
     // One launch (entropy lanes followed by the predictor waves, producer/consumer through HBM) where the chains are few
     // enough that a stage is as slow as its longest serial chain; separate launches where every kernel fills the machine by
     // itself (no polling, no release fence per publish).  Measured, fused / separate, 16-bit stereo packets (round 3, HEAD;
@@ -1613,35 +1580,19 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     // 34 000 2.84 / 2.88, 125 000 17.6 (round 1) / 5.3.  Option dec_fused (ALAC_HIP_DEC_FUSED) = 0 / 1 forces.
     const int forced = V.d.optFused;
     const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
-    if (fused && V.d.optLocal != 0) {
+    if (fused) {
         const uint32_t nEntWg = (da.numPackets + kFusedPpw - 1) / kFusedPpw;
         hipLaunchKernelGGL(k_dec_fused_wg, dim3(nEntWg + (da.numPackets + 3) / 4), dim3(256), 0, st, V, nEntWg);
-    } else if (fused) {
-        if (!useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, st);
-        // predictor waves per entropy wave: 64 packets x channels / 32 chains, and enough of them for all of nUnpc
-        uint32_t per = 2 * da.numChannels;
-        while ((uint64_t)nEnt * per < nUnpc) per++;
-        const uint64_t workers = (uint64_t)nEnt * (per + 1) + da.numPackets;
-        hipLaunchKernelGGL(k_dec_fused, dim3((uint32_t)((workers + kDecWavesPerWg - 1) / kDecWavesPerWg)), dim3(64 * kDecWavesPerWg), 0, st, V,
-                           nEnt, nUnpc, per);
     } else {
         hipLaunchKernelGGL(k_dec_raw, dim3(da.numPackets < 4096u ? da.numPackets : 4096u), dim3(256), 0, st, V);
-        const bool wide = V.d.optWide != 0;
         // deferred residual stores, four 16-byte stores per round of sixteen consecutive residuals (round 2, 4-byte stores:
         // paid only up to two entropy waves per SIMD; with the wide stores, measured whole decode pass at 125 000 / 250 000 /
         // 500 000 packets: 9.31 -> 8.19, 19.4 -> 14.2, 38.1 -> 26.5 ms — the kernel was bound by the number of store
         // instructions whose 64 lanes hit 64 different cache lines, which a CU's address path takes one line at a time)
-        if (wide)
-            hipLaunchKernelGGL(k_dec_entropy_wide, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
-        else
-            hipLaunchKernelGGL(k_dec_entropy, dim3(nEnt), dim3(64), 0, st, V);
-        if (wide) {
-            // chains sorted by tap count, one lane per chain (ALAC_HIP_DEC_WIDE=0: the two-lane kernel of the fused launch)
-            hipLaunchKernelGGL(k_dec_unpc_wide, dim3(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg),
-                               dim3(64 * kEntWavesPerWg), 0, st, V);
-        } else {
-            hipLaunchKernelGGL(k_dec_unpc_fast, dim3(nUnpc), dim3(64), 0, st, V);
-        }
+        hipLaunchKernelGGL(k_dec_entropy_wide, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
+        // chains sorted by tap count, one lane per chain
+        hipLaunchKernelGGL(k_dec_unpc_wide, dim3(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg),
+                           dim3(64 * kEntWavesPerWg), 0, st, V);
     }
     hipLaunchKernelGGL(k_dec_unpc, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
     switch (da.bitDepth) {
@@ -1665,7 +1616,7 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
     // publish every (mask + 1) rounds of 16 residuals: workgroup-local followers 8 (a publish only waits for the wave's own
     // stores; measured at 10 000 packets, mask 31 / 15 / 7 / 3 / 1: 1.749 / 1.723 / 1.717 / 1.717 / 1.729 ms), followers anywhere
     // on the chip 32 (every publish is an L2 write-back)
-    V.pubMask = da.optPubMask != 0xffffffffu ? da.optPubMask : (da.optLocal != 0 ? 7u : 31u);
+    V.pubMask = 7u;
     V.elemBit = nullptr;
     V.mismatch = nullptr;
     V.lists = V.pairs = 0;  // decode_v1_pass decides

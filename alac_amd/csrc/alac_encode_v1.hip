@@ -40,18 +40,6 @@ bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOpt
     return (uint64_t)numSegments * (channels > 2 ? 2 : channels) > 65536;
 }
 
-// overlapped sub-batches: as requested (ALAC_HIP_SUBBATCH), one by default.  Measured at 125 000 packets in the
-// throughput regime: 1 -> 11.6 ms, 2 -> 12.3 ms, 4 -> 13.6 ms (the halves' kernels get in each other's way more than
-// they fill each other's tails; the two packet classes of the final pass side by side do that job better); at 10 000
-// packets every kernel is bound by one wave's latency and splitting gains nothing either.
-uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels)
-{
-    (void)channels;
-    uint32_t H = requested ? requested : 1u;
-    while (H > 1 && numSegments < H * 256) H >>= 1;  // not worth splitting small batches
-    return H;
-}
-
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
                             const V1Buffers &vb, const V1Streams &vs, uint32_t numPackets, uint32_t maxSegPackets,
                             hipStream_t st, hipEvent_t *ev)
@@ -80,15 +68,11 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     A.dumpSlot = numPackets * 2;
     {
         // Latency regime (about one wave per SIMD: up to ~2 x 1024 x 32 chains): idle lanes should not slow their
-        // wave down.  With many waves per SIMD the machine is throughput bound and the extra work of idle lanes
-        // costs more than the checked paths (measured: 125 000 packets 18.6 ms vs 20.3 ms).  ALAC_HIP_IDLEFAST=0/1 forces.
-        const int forced = vb.opt.idleFast;
+        // wave down (idleFast).  With many waves per SIMD the machine is throughput bound and the extra work of idle lanes
+        // costs more than the checked paths (measured: 125 000 packets 18.6 ms vs 20.3 ms).
         const uint64_t chains = (uint64_t)ea.numSegments * channels;
-        A.idleFast = forced >= 0 ? (uint32_t)forced : (chains <= 65536 ? 1u : 0u);
-        const int forced81 = vb.opt.wide81;
         A.thru = v1_throughput_regime(ea.numSegments, channels, vb.opt) ? 1u : 0u;
-        A.wide81 = forced81 >= 0 ? (uint32_t)forced81 : A.thru;
-        if (forced < 0) A.idleFast = A.thru ? 0u : 1u;
+        A.idleFast = A.thru ? 0u : 1u;
         const int forcedNarrow = vb.opt.narrow;
         A.narrow = forcedNarrow >= 0 ? (uint32_t)forcedNarrow : (chains <= 4096 ? 1u : 0u);
     }
@@ -111,9 +95,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         // codes the rest: both waves finish together at ~2/3 of the frame; whole 48-residual iterations of the coder loop
         A.splitAt = (ea.frameSize * 2 / 3) / 48 * 48;
     }
-    {
-        A.pubMask = vb.opt.pubFence ? (0x80000000u | 3u) : 0u;
-    }
+    A.pubMask = 0;  // producers publish after every tile, rows written through (a release fence per publish cost ~11 us)
     A.flags2 = vb.flags;
     A.dbg = vb.opt.debugWaves ? vb.rowReady : nullptr;  // (the row-ready words are only used by chained tiny batches)
     A.foldDecide = 0;
@@ -121,7 +103,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
     // packet position take init_coefs as constants (load_row) instead of a k_init_state launch writing them first
     A.virgin = (!vb.stateInitialised && vb.stateInternal) ? 1u : 0u;
     if (vb.opt.fastMode && channels == 2) A.virgin = 0;  // no search launch takes init_coefs as constants there: write the rows
-    if (!vb.stateInitialised && (!A.virgin || vb.opt.initState))
+    if (!vb.stateInitialised && !A.virgin)
         hipLaunchKernelGGL(k_init_state, dim3((ea.numSegments * 64 + 255) / 256), dim3(256), 0, st, vb.state,
                            ea.numSegments);
 #define V1_CASE(D)                                                                                   \

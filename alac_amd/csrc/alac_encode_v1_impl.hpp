@@ -344,6 +344,11 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
 // ---- interior fast path of the staging (tile and its history fully inside every packet of the
 // wave): everything that does not change from tile to tile is computed once per pass, and a tile costs one
 // few vector loads plus the mix and the LDS writes per task — no bounds checks, no branches.
+// (Round 4 measured a COMPACT form of this plan for the 64-chains-per-wave kernels — a 32-bit offset from a wave-uniform base,
+// the LDS cell and the mixRes per task, 18 instead of 42 registers — because the compiler spills the 64-bit task addresses there
+// (256-register budget).  tools/scratch_sites.py shows why it changed nothing: the spilled values are reloaded in the per-PASS
+// set-up, never inside a tile loop; 125 000 packets 9.20 ms compact against 9.13 ms, FETCH_SIZE of k_search1_lane 1.436 GB
+// either way.  Not kept.)
 template <int CH, int LPC>
 struct StagePlan {
     static constexpr int ITERS = StageRegs<CH, LPC>::ITERS;
@@ -771,10 +776,10 @@ __global__ __launch_bounds__(64, L == 1 ? 2 : 1) void k_lms_search1(V1Args A)
 // ---- k_lms_search2: converge passes for numUV = 4 (row 3, one lane per chain) and 8 (row 7, two lanes per
 // chain) in one launch: the first nb3 workgroups take the 4-tap rows (codec/ALACEncoder.cu:420-431; mono :881-893)
 // RS = 0: row 3 (numUV = 4), RS = 1: row 7 (numUV = 8); T taps per lane x LPC lanes per chain
-// PUB (k_search2_fused): the last pass stores its rows written through and publishes them tile by tile in *flag for the count
-// waves of the same launch
-template <int DEPTH, int CH, int RS, int T, int LPC, bool PUB = false>
-__device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane, uint32_t *flag = nullptr)
+// (round 3 measured the counts as trailing consumers of this launch — 0.231 ms against 0.152 + 0.082 separate — and round 4
+// removed that variant)
+template <int DEPTH, int CH, int RS, int T, int LPC>
+__device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A, uint32_t block, int lane)
 {
     constexpr int SLOTS = 64 / LPC;
     constexpr int rs = RS;
@@ -798,20 +803,10 @@ __device__ __forceinline__ void search2_body(LmsShared<LPC> &sh, const V1Args &A
         const uint32_t num = (CH == 1 && last) ? n8 : n32;  // mono: the last pass runs N/8 (:893)
         uint32_t P = num > (uint32_t)(J.na + 1) ? num : (uint32_t)(J.na + 1);  // positions pc_block writes ...
         P = P < n8 ? P : n8;                                                   // ... that dyn_comp will read
-        if constexpr (PUB) {
-            if (last)
-                lms_pass<DEPTH, CH, LPC, true>(sh, A, J, a, num, P, true, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
-                                               lane, flag, 0, &head, 2);
-            else
-                lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, false, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain, lane,
-                                         nullptr, 0, &head, pass == 0 ? 1 : 2);
-        } else {
-            lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
-                                     lane, nullptr, 0, &head, pass == 0 ? 1 : 2);
-        }
+        lms_pass<DEPTH, CH, LPC>(sh, A, J, a, num, P, last, A.resB, 2ull * A.chainsPad, (uint32_t)rs * A.chainsPad + chain,
+                                 lane, nullptr, 0, &head, pass == 0 ? 1 : 2);
     }
     store_row<LPC>(J, a, lane);
-    if constexpr (PUB) publish_rows(flag, 0xffffffffu, lane, (A.pubMask >> 31) != 0, A.ho.lose);  // nothing more will come
 }
 
 // <T3, L3>: mapping of the 4-tap rows, <T7, L7>: of the 8-tap rows (<4, 1> and <4, 2>; <2, 2> and <2, 4> for tiny batches)
@@ -1041,47 +1036,10 @@ __global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_gol_count2_w(V1Args A, 
     count2_body<CH>(A, A.S.segBegin * CH + (W.id % cblocks) * 64u + (uint32_t)W.lane, W.id / cblocks, chanBits, recip, NoWait());
 }
 
-// ---- k_search2_fused: k_lms_search2 and k_gol_count2 in one launch (latency regime).  Workgroups [0, nb3) walk the 4-tap
-// rows (64 chains each), [nb3, nPred) the 8-tap rows (32 chains each); the last of their 8 converge passes stores its rows
-// written through and publishes them tile by tile.  The remaining 2 * cblocks workgroups are the count waves (row set rs,
-// 64 chains each): they follow their producers through the P2 rows of that pass and then walk the stale tail in the mixRes = 4
-// plane of the search launch before (complete long ago).  A count that ran as its own launch only started when the slowest
-// predictor wave had finished all eight passes.
-template <int DEPTH, int CH>
-__global__ __launch_bounds__(64 * kWavesPerWg, 1) void k_search2_fused(V1Args A, uint32_t nb3, uint32_t nPred, uint32_t cblocks, uint32_t chanBits)
-{
-    __shared__ union {
-        LmsShared<1> s1;
-        LmsShared<2> s2;
-    } shAll[kWavesPerWg];
-    __shared__ uint32_t recipAll[kWavesPerWg][20];
-    const Worker W = worker_id();
-    if (W.id >= nPred + 2 * cblocks) return;
-    auto &sh = shAll[W.slot];
-    uint32_t *recip = recipAll[W.slot];
-    const int lane = W.lane;
-    uint32_t *flags = A.flags2;
-    if (W.id < nb3) {
-        search2_body<DEPTH, CH, 0, 4, 1, true>(sh.s1, A, W.id, lane, flags + W.id);
-    } else if (W.id < nPred) {
-        search2_body<DEPTH, CH, 1, 4, 2, true>(sh.s2, A, W.id - nb3, lane, flags + W.id);
-    } else {
-        gol_table_init(recip, lane);
-        lds_order();
-        const uint32_t idx = W.id - nPred, rs = idx / cblocks, w = idx % cblocks;
-        RowWait wait;
-        if (rs == 0) wait.producers(flags, w, 1, nb3);
-        else wait.producers(flags, nb3 + 2 * w, 2, nPred);
-        wait.avail = 0;
-        wait.base = 0;
-        wait.ho = A.ho;
-        count2_body<CH>(A, A.S.segBegin * CH + w * 64u + (uint32_t)lane, rs, chanBits, recip, wait);
-    }
-}
-
 // SetFastMode (stereo): what EncodeStereoFast fixes instead of searching (codec/ALACEncoder.cu:613-618) — mixRes 0, numU = numV = 8,
 // no escape estimate (the escape decision comes from the bits written, :705-729 = k_finalize's rule) — and the header
 // coefficients = row 7 as it stands before the pass (:655-671)
+#ifdef ALAC_V1_COMMON_TU
 static __global__ void k_decide_fast(V1Args A)
 {
     const uint32_t seg = A.S.segBegin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1098,6 +1056,7 @@ static __global__ void k_decide_fast(V1Args A)
     rec->numSamples = N;
     rec->escape = 0;
 }
+#endif
 
 // numU / numV, escape estimate (codec/ALACEncoder.cu:438-461, mono :899-915), header coefficients
 template <int DEPTH, int CH>
@@ -1694,79 +1653,22 @@ __device__ __forceinline__ void class_job(const V1Args &A, uint32_t col, uint32_
     J.row = A.state + (uint64_t)J.seg * 64 + J.ch * 32 + (J.na == 8 ? 16 : 0);
 }
 
-// The class kernels run as separate launches (throughput regime: every kernel fills the machine on its own, plain
-// coalesced stores, no polling).  A fused producer/consumer form of this pass was measured in the latency regime
-// (10 000 packets) and lost to k_final_fused, 0.97 vs 0.77 ms: a third hot loop body in one launch does not fit the
-// instruction cache the workgroups of a CU share.
-//
-// region 0 = the 8-tap class (columns [0, base4)), region 1 = the 4-tap class (columns [base4, nCols)); the grid is
-// sized for the worst case on the host (the class counts live on the device), surplus workgroups leave at once
-template <int DEPTH, int CH, int T, int L>
-__global__ __launch_bounds__(64, 2) void k_class_pred(V1Args A, uint32_t region)
+// ---- k_class_final: final predictor pass AND final entropy coder of a chain in ONE lane (throughput regime), one launch per
+// packet class (region 0 = the 8-tap class, columns [0, base4); region 1 = the 4-tap class, [base4, nCols); the grid is sized
+// for the worst case on the host — the class counts live on the device — and surplus workgroups leave at once).
+// The lane codes each 32-step tile straight from its own LDS row, where the predictor leaves the residuals in place
+// (alac_lms.hpp / lms_pass): no residual plane, no transposed flush, no row loads, and the wave carries two independent serial
+// recurrences (sign-LMS and the Golomb mean tracker) instead of one.  (Round 3 also had the predictor and the coder as two
+// launches with a 4.1 GB plane between them, and a four-waves-per-workgroup form that gained 0.4 %: both removed in round 4.
+// A fused producer/consumer form of this pass lost to k_final_fused in the latency regime, 0.97 vs 0.77 ms: a third hot loop
+// body in one launch does not fit the instruction cache the workgroups of a CU share.)
+template <int DEPTH, int CH, int T>
+__global__ __launch_bounds__(64, 2) void k_class_final(V1Args A, uint32_t chanBits, uint32_t region)
 {
-    __shared__ LmsShared<L> sh;
+    __shared__ LmsShared<1> sh;
+    __shared__ uint32_t recip[20];
     const int lane = threadIdx.x;
-    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
-    constexpr uint32_t C = 64 / L;  // columns per predictor wave
-    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * C;
-    if (col0 >= (region ? nCols : base4)) return;
-    ChainJob J;
-    int best;
-    const uint32_t col = col0 + (uint32_t)(lane / L);
-    class_job<CH>(A, col, region ? base4 + n4 : n8, J, best);
-    const uint32_t N = J.N;
-    int32_t a[T];
-    load_row<L>(J, a, lane);
-    lms_setup<L>(sh, J, best, lane);
-    lms_pass<DEPTH, CH, L, false, true>(sh, A, J, a, N, N, true, A.resC, A.colsPad, col, lane);
-    store_row<L>(J, a, lane);
-}
-
-// final entropy coding of the compacted columns, one lane per chain; LAZY: see golf_put
-template <int CH, bool LAZY>
-__global__ __launch_bounds__(64) void k_class_coder(V1Args A, uint32_t chanBits, uint32_t region)
-{
-    __shared__ uint32_t recip[17];
-    const int lane = threadIdx.x;
-    const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
-    const uint32_t col0 = (region ? base4 : 0u) + blockIdx.x * 64u;
-    if (col0 >= (region ? nCols : base4)) return;
-    gol_table_init(recip, lane);
-    __syncthreads();
-    const uint32_t col = col0 + lane;
-    const uint32_t chain = col < (col0 < base4 ? n8 : base4 + n4) ? A.colChain[col] : kNoChain;
-    uint32_t p = 0, N = 0;
-    const bool active = chain != kNoChain && seg_packet(A.S, chain / CH, p, N);
-    PacketRec *rec = A.recs + p;
-    const uint32_t c = active ? chain % CH : 0;
-    const uint32_t n = active ? N : 0;
-    GolF g;
-    golf_reset(g);
-    uint32_t *slot = A.bitWords + (active ? (uint64_t)p * 2 + c : (uint64_t)A.dumpSlot + (lane & 1)) * A.wcap;
-    golf_open(g, slot, A.wcap);
-    golf_stream<true, true, NoWait, LAZY>(g, n, wave_max(n), chanBits, recip, one_plane(A.resC, A.colsPad, col), NoWait(),
-                                          A.idleFast != 0);
-    golf_flush<true, LAZY>(g);
-    if (active) rec->c[c].bits = golf_written_bits<LAZY>(g, slot);
-}
-
-// ---- k_class_final: final predictor pass AND final entropy coder of a chain in ONE lane (throughput regime).
-// k_class_pred<.., T, 1> and k_class_coder give lane i the same column col0 + i, so the residual plane between them
-// (4.1 GB written and read again per 125 000-packet pass) only moved every lane's residuals from the lane to itself.
-// Here the lane codes each 32-step tile straight from its own LDS row (where the predictor leaves the residuals in place,
-// alac_lms.hpp / lms_pass): no resC, no transposed flush, no row loads, and the wave carries two independent serial
-// recurrences (sign-LMS and the Golomb mean tracker) instead of one.
-// WG = 1: single-wave workgroups; WG = 4: workgroups of four workers (worker_id): every workgroup puts exactly one wave on each
-// SIMD of its CU, so the SIMDs of a CU carry equal numbers of these equally long waves whatever the CU's wave allocator does
-template <int DEPTH, int CH, int T, int WG = 1>
-__global__ __launch_bounds__(64 * WG, 2) void k_class_final(V1Args A, uint32_t chanBits, uint32_t region)
-{
-    __shared__ LmsShared<1> shAll[WG];
-    __shared__ uint32_t recipAll[WG][20];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wslot = threadIdx.x >> 6, wid = blockIdx.x * (uint32_t)WG + wslot;
-    LmsShared<1> &sh = shAll[wslot];
-    uint32_t *recip = recipAll[wslot];
+    const uint32_t wid = blockIdx.x;
     const uint32_t n8 = A.cls->n8, n4 = A.cls->n4, base4 = A.cls->base4, nCols = A.cls->nCols;
     const uint32_t col0 = (region ? base4 : 0u) + wid * 64u;
     if (col0 >= (region ? nCols : base4)) return;
@@ -1823,45 +1725,42 @@ __global__ void k_finalize(PacketRec *recs, uint32_t *packetBytes, uint32_t numP
 // ================================================================================================
 // launcher
 // ================================================================================================
+// Kernels that do not depend on the bit depth (the Golomb counts and the stagewise final coder, the class layout of the
+// throughput regime, the splice of the split coder, SetFastMode's decision) are compiled ONCE, in alac_encode_v1_common.hip,
+// which defines these launch wrappers; the four per-depth translation units only call them.  (Round 3 instantiated every one
+// of them in each of the four: 48 of the library's kernels were copies.)
+void v1c_decide_fast(uint32_t nseg, hipStream_t st, const V1Args &A);
+void v1c_gol_count1(int ch, uint32_t cblocks, hipStream_t st, const V1Args &A, uint32_t chanBits);
+void v1c_gol_count2(int ch, uint32_t cblocks, hipStream_t st, const V1Args &A, uint32_t chanBits);
+void v1c_gol_count2_w(int ch, uint32_t cblocks, hipStream_t st, const V1Args &A, uint32_t chanBits);
+void v1c_class_layout(int ch, uint32_t nseg, hipStream_t st, const V1Args &A, uint32_t *blockCnt);
+void v1c_splice_split(int ch, uint32_t nseg, hipStream_t st, const V1Args &A);
+void v1c_gol_final(int ch, uint32_t cblocks, hipStream_t st, const V1Args &A, uint32_t chanBits);
 template <int DEPTH, int CH>
 void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPackets, hipStream_t st, hipEvent_t *ev,
                      const PackArgs &pa, const V1Streams &vs, const AlacOptions &opt)
 {
     constexpr uint32_t chanBits = DEPTH - 8 * bytes_shifted(DEPTH) + (CH == 2 ? 1 : 0);
     const uint32_t nsegAll = A0.S.numSegments;
-    // Sub-batches: the predictor kernels saturate VALU issue while the Golomb kernels are bound by the
-    // latency of one serial chain per lane and leave most SIMDs idle, so sub-batch h+1 starts its predictor
-    // kernels as soon as sub-batch h has finished its first one and the two kinds of kernel overlap.
-    const uint32_t H = v1_sub_batches(nsegAll, vs.numSub, CH);
+    // (Overlapped sub-batches — halves of the batch on two streams — were measured in rounds 1-3 and lost in both regimes,
+    // 12.3 / 13.6 ms for 2 / 4 against 11.6 at 125 000 packets; removed in round 4.  The whole batch is one "sub-batch".)
     bool latFoldAny = false;
-    uint32_t per = ((nsegAll + H - 1) / H + 63) & ~63u;         // whole waves per sub-batch
-    if (H > 1) (void)hipEventRecord(vs.fork, st);
-    for (uint32_t h = 0; h < H; h++) {
+    {
         V1Args A = A0;
-        A.S.segBegin = h * per;
-        A.S.segEnd = (h + 1) * per < nsegAll ? (h + 1) * per : nsegAll;
-        if (A.S.segBegin >= A.S.segEnd) break;
-        // class layout of the final pass: every sub-batch compacts into its own window of columns
-        A.cls = A0.cls + h;
-        A.colChain = A0.colChain + (uint64_t)h * (per * CH + 128);
-        A.resC = A0.resC + (uint64_t)h * (per * CH + 128);
-        uint32_t *blockCnt = (uint32_t *)(A0.cls + kMaxSubBatches) + 2 * (A.S.segBegin / 1024 + h);
-        const uint32_t nseg = A.S.segEnd - A.S.segBegin;
+        A.S.segBegin = 0;
+        A.S.segEnd = nsegAll;
+        uint32_t *blockCnt = (uint32_t *)(A0.cls + 1);
+        const uint32_t nseg = nsegAll;
         const uint32_t cblocks = (nseg * CH + 63) / 64;
-        hipStream_t sh = h == 0 ? st : vs.side[h - 1];
-        if (h > 0) {
-            (void)hipStreamWaitEvent(sh, vs.fork, 0);
-            (void)hipStreamWaitEvent(sh, vs.stagger[h - 1], 0);  // first predictor kernel of sub-batch h-1 done
-        }
-        // stage events: sub-batch h records into ev + h * (kNumStages + 1) on its own stream
-        hipEvent_t *evh = ev ? ev + (size_t)h * (kNumStages + 1) : nullptr;
+        hipStream_t sh = st;
+        hipEvent_t *evh = ev;  // stage events of the predictor / Golomb stages: block 0 of ev
         // Chained tiny batches (a file = one chain of packets): packet position p + 1's mixRes search only needs the 8-tap
         // rows, which position p leaves alone once its own search is over unless it runs its FINAL pass on them — so the
         // positions alternate between two streams, the search launch of p + 1 starts when decide2 of p has run and its
         // predictor waves wait, per chain, for rows that p's final pass still owns (rowReady).  The rest of p + 1 waits for
         // p's final pass.  58-75 % of packets choose 4 taps on both channels: their successor's search (a third of a
         // position's serial chain) disappears behind the final pass.
-        const bool overlap = opt.overlapPos != 0 && !(CH == 2 && opt.fastMode) && CH == 2 && H == 1 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
+        const bool overlap = opt.overlapPos != 0 && !(CH == 2 && opt.fastMode) && CH == 2 && maxSegPackets > 1 && A.narrow != 0 && A.thru == 0 &&
                              A.S.frameSize / 8 < 65536u && opt.fused != 0;
         if (overlap) {
             A.rowReady = A0.ovRowReady;
@@ -1886,7 +1785,7 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             //              (fewest instructions per chain step), the final pass runs per packet class and the coder
             //              stores only completed words.  125 000 packets: 15.8 -> 10.1 ms.
             const bool thru = A.thru != 0;
-            const bool fuse = fused && H == 1 && !thru;  // flag words are indexed by workgroup: one sub-batch only
+            const bool fuse = fused && !thru;
             const uint32_t nLms = (nseg * CH + 31) / 32;
             // Tiny batches (a single chained file, a few hundred files side by side): the chains do not even fill one
             // wave per SIMD at 16 chains per wave, so a chain gets FOUR lanes x 2 taps (two lanes for the 4-tap rows of the
@@ -1895,13 +1794,11 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             const uint32_t nLms16 = (nseg * CH + 15) / 16;
             A.virgin = firstPos ? A0.virgin : 0u;
             // Latency regime, two lanes per chain: the small launches between the big ones are folded away ("fold" = 0 keeps
-            // them): the converge passes and their counts share a launch (k_search2_fused), the final launch decides numU / numV /
-            // escape and the packet sizes itself (k_final_fused<.., FOLD>), and ONE memset clears the progress words of all three
-            // producer/consumer launches of the position.
-            // (experiments: bit 0 of "fold" = the converge launch, bit 1 = the final launch, bit 2 = one memset for all flag words)
+            // them): the final launch decides numU / numV / escape and the packet sizes itself (k_final_fused<.., FOLD>), and ONE
+            // memset clears the progress words of both producer/consumer launches of the position.
             const bool fast = CH == 2 && opt.fastMode != 0;  // SetFastMode: no search passes at all (mono has no fast form)
             const bool foldOk = fuse && !narrow && !fast;
-            const bool latFold2 = foldOk && (opt.fold & 1), latFold = foldOk && (opt.fold & 2), oneMemset = foldOk && (opt.fold & 4);
+            const bool latFold = foldOk && opt.fold != 0, oneMemset = latFold;
             latFoldAny = latFoldAny || latFold;
             if (foldOk) {
                 A.flags2 = A0.flags + ((A0.chainsPad / 32 + 4) & ~3u);   // behind the (at most chains / 32) words of the search launch
@@ -1915,10 +1812,9 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                     (void)hipEventRecord(e[kStageLms2], sp);
                     (void)hipEventRecord(e[kStageGol2], sp);
                 }
-                hipLaunchKernelGGL(k_decide_fast, dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
+                v1c_decide_fast(nseg, sp, A);
             } else if constexpr (CH == 2) {
-                const bool wide = A.wide81 != 0;
-                const uint32_t nLms1 = wide ? cblocks : nLms;
+                const uint32_t nLms1 = nLms;
                 // the search progress word is (pass << 16) + rows: rows of a pass must stay below 2^16
                 if (fuse && narrow && A.S.frameSize / 8 < 65536u) {
                     (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
@@ -1927,29 +1823,18 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else if (fuse && A.S.frameSize / 8 < 65536u) {
                     if (!oneMemset) (void)hipMemsetAsync(A.flags, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
-                    if (wide)
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 8, 1>), dim3((nLms1 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms1,
-                                           cblocks, chanBits);
-                    else if (opt.countWalk)
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2, true>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
-                                           dim3(64 * kWavesPerWg), 0, sp, A, nLms1, cblocks, chanBits);
-                    else
-                        hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2>), dim3((nLms1 + 5 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms1,
-                                           cblocks, chanBits);
+                    // ONE count wave per 64 chains walks the five planes behind its two producers (WALK)
+                    hipLaunchKernelGGL((k_search1_fused<DEPTH, 4, 2, true>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
+                                       dim3(64 * kWavesPerWg), 0, sp, A, nLms1, cblocks, chanBits);
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
-                } else if (thru && wide && opt.searchFused) {
+                } else if (thru) {
                     // predictor passes and their bit counts in one lane: no residual planes except the mixRes = 4 pass's
                     hipLaunchKernelGGL((k_search1_lane<DEPTH>), dim3(cblocks), dim3(64), 0, sp, A, chanBits);
-                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
                 } else {
-                    if (wide)
-                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 8, 1>), dim3(nLms1), dim3(64), 0, sp, A);
-                    else
-                        hipLaunchKernelGGL((k_lms_search1<DEPTH, 4, 2>), dim3(nLms1), dim3(64), 0, sp, A);
-                    if (firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
+                    hipLaunchKernelGGL((k_lms_search1<DEPTH, 4, 2>), dim3(nLms1), dim3(64), 0, sp, A);
                     if (e) (void)hipEventRecord(e[kStageGol1], sp);
-                    hipLaunchKernelGGL(k_gol_count1<CH>, dim3(cblocks, 5), dim3(64), 0, sp, A, chanBits);
+                    v1c_gol_count1(CH, cblocks, sp, A, chanBits);
                 }
             } else if (e) {
                 (void)hipEventRecord(e[kStageGol1], sp);
@@ -1958,29 +1843,21 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             if (!fast) {
                 if (e) (void)hipEventRecord(e[kStageLms2], sp);
                 const uint32_t nb3 = (nseg * CH + 63) / 64, nb7 = (nseg * CH + 31) / 32;
-                if (latFold2) {
-                    if (!oneMemset) (void)hipMemsetAsync(A.flags2, 0, ((size_t)(nb3 + nb7) * 4 + 15) & ~(size_t)15, sp);
-                    hipLaunchKernelGGL((k_search2_fused<DEPTH, CH>), dim3((nb3 + nb7 + 2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nb3, nb3 + nb7, cblocks,
-                                       chanBits);
-                } else if (narrow)
+                if (narrow)
                     hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 2, 2, 2, 4>), dim3(nb7 + nLms16), dim3(64), 0, sp, A, nb7);
-                else if (thru && opt.searchFused)  // as below, and every lane counts its own residuals
+                else if (thru)  // 64 chains per wave for both rows, two waves per SIMD; every lane counts its own residuals
                     hipLaunchKernelGGL((k_search2_lane<DEPTH, CH>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3, chanBits);
-                else if (thru)  // 64 chains per wave for both rows, two waves per SIMD
-                    hipLaunchKernelGGL((k_lms_search2<DEPTH, CH, 4, 1, 8, 1, 2>), dim3(nb3 + nb3), dim3(64), 0, sp, A, nb3);
                 else if (fuse)  // latency regime: workers (one wave per SIMD by construction)
                     hipLaunchKernelGGL((k_lms_search2_w<DEPTH, CH>), dim3((3 * nb3 + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
                                        nb3, nb7);
                 else
                     hipLaunchKernelGGL((k_lms_search2<DEPTH, CH>), dim3(nb3 + nb7), dim3(64), 0, sp, A, nb3);
-                if (CH == 1 && firstPos && h + 1 < H) (void)hipEventRecord(vs.stagger[h], sp);
                 if (e) (void)hipEventRecord(e[kStageGol2], sp);
-                if (!latFold2 && (!(thru && opt.searchFused) || narrow)) {
+                if (!thru) {
                     if (fuse)
-                        hipLaunchKernelGGL(k_gol_count2_w<CH>, dim3((2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A,
-                                           cblocks, chanBits);
+                        v1c_gol_count2_w(CH, cblocks, sp, A, chanBits);
                     else
-                        hipLaunchKernelGGL(k_gol_count2<CH>, dim3(cblocks, 2), dim3(64), 0, sp, A, chanBits);
+                        v1c_gol_count2(CH, cblocks, sp, A, chanBits);
                 }
                 if (!latFold) hipLaunchKernelGGL((k_decide2<DEPTH, CH>), dim3((nseg + 255) / 256), dim3(256), 0, sp, A);
             }
@@ -1990,50 +1867,26 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 // final pass by packet class: compact the packets that still need it (k_class_count, k_class_assign), then per class the
                 // lane mapping that fits it — escaped packets cost nothing, all-4-tap packets run 64 chains per wave
                 const uint32_t cwaves = (((nseg * CH + 63) & ~63u) + 64) / 64;  // worst case per region, + the padding
-                hipLaunchKernelGGL(k_class_count<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sp, A, blockCnt);
-                hipLaunchKernelGGL(k_class_assign<CH>, dim3((nseg + 1023) / 1024), dim3(1024), 0, sp, A, blockCnt);
+                v1c_class_layout(CH, nseg, sp, A, blockCnt);
                 // the two classes are independent from here on: predictor -> coder of the 4-tap class on a side stream beside
                 // those of the 8-tap class.  Each kernel alone leaves the machine unevenly filled (a few thousand waves of
                 // ~1 ms each on 1024 SIMDs, LDS-limited to 6 predictor waves per CU); side by side the light coder waves
                 // of one class fill what the predictor waves of the other cannot use.
-                // (with overlapped sub-batches the other sub-batch plays that part and the side streams are theirs)
-                const bool two = H == 1;
-                hipStream_t s2 = two ? vs.side[0] : sh;
-                if (two) {
-                    (void)hipEventRecord(vs.fork, sp);
-                    (void)hipStreamWaitEvent(s2, vs.fork, 0);
-                }
-                if (opt.classFused) {
-                    // predictor and coder of a chain in one lane: no residual plane (k_class_final)
-                    if (opt.thruWg4) {
-                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8, 4>), dim3((cwaves + 3) / 4), dim3(256), 0, sp, A, chanBits, 0u);
-                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4, 4>), dim3((cwaves + 3) / 4), dim3(256), 0, s2, A, chanBits, 1u);
-                    } else {
-                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
-                        hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
-                    }
-                    if (two) {
-                        (void)hipEventRecord(vs.join[0], s2);
-                        (void)hipStreamWaitEvent(sh, vs.join[0], 0);
-                    }
-                    if (e) (void)hipEventRecord(e[kStageGol3], sp);
-                } else {
-                    hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 8, 1>), dim3(cwaves), dim3(64), 0, sp, A, 0u);
-                    hipLaunchKernelGGL((k_class_pred<DEPTH, CH, 4, 1>), dim3(cwaves), dim3(64), 0, s2, A, 1u);
-                    if (e) (void)hipEventRecord(e[kStageGol3], sp);
-                    hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
-                    hipLaunchKernelGGL((k_class_coder<CH, true>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
-                    if (two) {
-                        (void)hipEventRecord(vs.join[0], s2);
-                        (void)hipStreamWaitEvent(sh, vs.join[0], 0);
-                    }
-                }
+                hipStream_t s2 = vs.side[0];
+                (void)hipEventRecord(vs.fork, sp);
+                (void)hipStreamWaitEvent(s2, vs.fork, 0);
+                // predictor and coder of a chain in one lane: no residual plane (k_class_final)
+                hipLaunchKernelGGL((k_class_final<DEPTH, CH, 8>), dim3(cwaves), dim3(64), 0, sp, A, chanBits, 0u);
+                hipLaunchKernelGGL((k_class_final<DEPTH, CH, 4>), dim3(cwaves), dim3(64), 0, s2, A, chanBits, 1u);
+                (void)hipEventRecord(vs.join[0], s2);
+                (void)hipStreamWaitEvent(sh, vs.join[0], 0);
+                if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else if (narrow) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms16 * 4 + 15) & ~(size_t)15, sp);
                 if (A.bitWordsB && A.splitAt >= 48) {
                     hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4, true>), dim3((nLms16 + 2 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg), 0, sp, A, nLms16,
                                        chanBits, cblocks, nLms16 + 2 * cblocks);
-                    hipLaunchKernelGGL(k_splice_split<CH>, dim3(nseg * CH), dim3(64), 0, sp, A);
+                    v1c_splice_split(CH, nseg, sp, A);
                 } else {
                     hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 2, 4>), dim3((5 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
                                        dim3(64 * kWavesPerWg), 0, sp, A, nLms16, chanBits, 0u, 5 * cblocks);
@@ -2045,17 +1898,17 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
                 // with the interleaved roles: coder waves 2.20 M instead of 1.70 M cycles, launch 0.95 instead of 0.75 ms — the
                 // queue's selects and branch cost a lone wave more than the scattered stores it saves)
                 hipLaunchKernelGGL((k_final_fused<DEPTH, CH, 4, 2, false, true>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg),
-                                   dim3(64 * kWavesPerWg), (size_t)opt.ldsPad, sp, A, nLms, chanBits, 0u, 3 * cblocks);
+                                   dim3(64 * kWavesPerWg), 0, sp, A, nLms, chanBits, 0u, 3 * cblocks);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else if (fuse) {
                 (void)hipMemsetAsync(A.flagsF, 0, ((size_t)nLms * 4 + 15) & ~(size_t)15, sp);
                 hipLaunchKernelGGL((k_final_fused<DEPTH, CH>), dim3((3 * cblocks + kWavesPerWg - 1) / kWavesPerWg), dim3(64 * kWavesPerWg),
-                                   (size_t)opt.ldsPad, sp, A, nLms, chanBits, 0u, 3 * cblocks);
+                                   0, sp, A, nLms, chanBits, 0u, 3 * cblocks);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
             } else {
                 hipLaunchKernelGGL((k_lms_final<DEPTH, CH>), dim3((nseg * CH + 31) / 32), dim3(64), 0, sp, A);
                 if (e) (void)hipEventRecord(e[kStageGol3], sp);
-                hipLaunchKernelGGL(k_gol_final<CH>, dim3(cblocks), dim3(64), 0, sp, A, chanBits);
+                v1c_gol_final(CH, cblocks, sp, A, chanBits);
             }
             if (overlap) {
                 (void)hipEventRecord(vs.join[pos & 1], sp);
@@ -2063,13 +1916,9 @@ void launch_v1_typed(const V1Args &A0, uint32_t numPackets, uint32_t maxSegPacke
             }
             if (e) (void)hipEventRecord(e[kStageScan], sh);  // end marker of this sub-batch's last stage
         }
-        if (h > 0) {
-            (void)hipEventRecord(vs.join[h - 1], sh);
-            (void)hipStreamWaitEvent(st, vs.join[h - 1], 0);
-        }
     }
-    // sizes, scan, pack: once, on the caller's stream; events live in the slot after the last sub-batch
-    hipEvent_t *evt = ev ? ev + (size_t)vs.maxSub * (kNumStages + 1) : nullptr;
+    // sizes, scan, pack: once, on the caller's stream; their events live in block 1 of ev
+    hipEvent_t *evt = ev ? ev + (size_t)(kNumStages + 1) : nullptr;
     if (evt) (void)hipEventRecord(evt[kStageScan], st);
     if (!latFoldAny)  // (the folded final launches have written the packet sizes)
         hipLaunchKernelGGL((k_finalize<DEPTH, CH>), dim3((numPackets + 255) / 256), dim3(256), 0, st, A0.recs, A0.packetBytes,

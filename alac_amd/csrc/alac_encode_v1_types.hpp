@@ -52,7 +52,6 @@ struct V1Args {
     uint32_t pubMask;      // producers publish after every (low byte + 1) tiles; bit 31: with a release fence
     uint32_t idleFast;     // 1: lanes without work do not force the checked paths (latency regime, see launcher)
     HandoffCtl ho;         // error word / spin bound / test switch of the in-launch hand-offs
-    uint32_t wide81;       // 1: 8-tap rows of the searches run with all taps in one lane (throughput regime)
     uint32_t thru;         // 1: throughput regime (see launch_v1_typed)
     uint32_t narrow;       // 1: tiny batch: four lanes per chain
     // chained tiny batches: the mixRes search of packet position p + 1 runs beside the final pass of position p

@@ -92,41 +92,29 @@ struct HandoffCtl {
 // names are only the DEFAULTS a context starts from, read once in alac_hip_create).  -1 = automatic (chosen per call
 // from the batch shape).
 struct AlacOptions {
-    int32_t thru = -1;         // "thru"         ALAC_HIP_THRU        encode: throughput (1) / latency (0) regime
-    int32_t idleFast = -1;     // "idlefast"     ALAC_HIP_IDLEFAST    lanes without work do not force the checked paths
-    int32_t wide81 = -1;       // "wide81"       ALAC_HIP_WIDE81      8-tap search rows with all taps in one lane
-    int32_t narrow = -1;       // "narrow"       ALAC_HIP_NARROW      tiny batches: four lanes per chain
+    int32_t thru = -1;         // "thru"         ALAC_HIP_THRU        encode: throughput (1) / latency (0) regime, -1 = by batch size
+    int32_t narrow = -1;       // "narrow"       ALAC_HIP_NARROW      tiny batches: four lanes per chain, -1 = by batch size
     int32_t splitCoder = 1;    // "split_coder"  ALAC_HIP_SPLIT_CODER tiny batches: final coder of a chain on two waves
-    int32_t pubFence = 0;      // "pubfence"     ALAC_HIP_PUBFENCE    release fence per publish (instead of write-through rows)
     int32_t overlapPos = 1;    // "overlap_pos"  ALAC_HIP_OVERLAP_POS chained batches: position p + 1's search beside p's final pass
-    int32_t fused = 1;         // "fused"        ALAC_HIP_FUSED       producer/consumer launches (latency regime)
-    int32_t subBatch = 0;      // "subbatch"     ALAC_HIP_SUBBATCH    overlapped sub-batches (0 = default: one)
+    int32_t fused = 1;         // "fused"        ALAC_HIP_FUSED       producer/consumer launches (latency regime); 0 = one kernel per stage
+    int32_t fold = 1;          // "fold"         ALAC_HIP_FOLD        latency regime: decision and packet sizes inside the final launch
+    int32_t fastMode = 0;      // "fast_mode"    (no env)             ALACEncoder::SetFastMode: stereo elements without the search (EncodeStereoFast)
     int32_t laneEncoder = 0;   // "encoder_lane" ALAC_HIP_ENCODER=lane first-generation lane-per-chain encoder
     int32_t laneDecoder = 0;   // "decoder_lane" ALAC_HIP_DECODER=lane first-generation decoder
-    int32_t decFused = -1;     // "dec_fused"    ALAC_HIP_DEC_FUSED   decode: entropy lanes || predictor waves in one launch
-    int32_t decWide = 1;       // "dec_wide"     ALAC_HIP_DEC_WIDE    decode, separate launches: one lane per chain, sorted by taps
+    int32_t decFused = -1;     // "dec_fused"    ALAC_HIP_DEC_FUSED   decode: entropy wave + its predictor waves in one launch, -1 = by batch size
     int32_t decPair = 1;       // "dec_pair"     ALAC_HIP_DEC_PAIR    decode, separate launches, 16-bit stereo: the predictor lanes of a packet un-mix and write the PCM
-    int32_t decLocal = 1;      // "dec_local"    ALAC_HIP_DEC_LOCAL   fused decode: the followers of an entropy wave are waves of its workgroup (LDS progress, no L2 write-back)
-    int32_t decPubMask = -1;   // "dec_pubmask"  ALAC_HIP_DEC_PUBMASK fused decode: publish every (mask + 1) * 16 symbols (-1: 7 with dec_local, else 31)
     int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
-    int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  test switch: producers never publish
-    int32_t initState = 0;     // "init_state"   ALAC_HIP_INIT_STATE  1: k_init_state writes the workspace rows even where the kernels take
-                               //                                     init_coefs as constants (experiments)
-    int32_t countWalk = 1;     // "count_walk"   ALAC_HIP_COUNT_WALK  latency regime, mixRes search: one count wave per 64 chains walks the five planes
+    int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  TEST switch: producers never publish (results invalid by design)
     int32_t debugWaves = 0;    // "debug_waves"  wave placement / timing stamps of the fused final launch into the workspace (tools/wave_map.py)
-    int32_t ldsPad = 0;        // "lds_pad"      ALAC_HIP_LDS_PAD     dynamic LDS bytes added to the single-wave workgroups of the fused final
-                               //                                     launch (caps the workgroups a CU takes: experiments)
-    int32_t thruWg4 = 0;       // "thru_wg4"     ALAC_HIP_THRU_WG4    throughput regime: the class launches as 4-worker workgroups
-    int32_t fastMode = 0;      // "fast_mode"    (no env)             ALACEncoder::SetFastMode: stereo elements without the search (EncodeStereoFast)
-    int32_t fold = 6;          // "fold"         ALAC_HIP_FOLD        latency regime: converge passes || counts in one launch, decision and
-                               //                                     packet sizes inside the final launch, no k_init_state / k_decide* / k_finalize
-    int32_t searchFused = 1;   // "search_fused" ALAC_HIP_SEARCH_FUSED throughput regime: search passes + their bit counts in one lane
-    int32_t classFused = 1;    // "class_fused"  ALAC_HIP_CLASS_FUSED throughput regime: final predictor + coder of a chain in one lane
-    int32_t persist = -1;      // "persist"      ALAC_HIP_PERSIST     chained tiny batches: one persistent launch per batch
 };
 AlacOptions alac_options_from_env();
-// nullptr for an unknown key
-int32_t *alac_option_slot(AlacOptions &o, const char *key);
+struct AlacOptionKey {
+    const char *name;
+    int32_t AlacOptions::*slot;
+    int32_t lo, hi;  // accepted values
+};
+const AlacOptionKey *alac_option_keys(uint32_t *count);
+const AlacOptionKey *alac_option_find(const char *key);  // nullptr for an unknown key
 
 struct V1Buffers {
     AlacOptions opt;
@@ -142,27 +130,25 @@ struct V1Buffers {
     uint32_t chainsPad;
     void *cls;             // ClassInfo of the class-based final pass (alac_encode_v1.hip)
     uint32_t *colChain;    // [colsPad]
-    uint32_t colsPad;      // chainsPad + 128 per possible sub-batch: row stride of resC
+    uint32_t colsPad;      // chainsPad + 256: the two class regions of the final pass are padded to whole waves
     uint32_t *bitWordsB;   // tiny batches: bit words of the second coder wave (same layout as EncodeArgs::bitWords), else null
     uint32_t *bitsB;       // [2 * numPackets + 2]
 };
-// side streams and fork/join events for the sub-batch overlap (owned by the context)
-constexpr uint32_t kMaxSubBatches = 8;
+// side stream and fork/join events (owned by the context): the second packet class of the throughput regime's final pass runs
+// beside the first, and consecutive packet positions of a chained tiny batch alternate between the two streams
+constexpr uint32_t kSideEvents = 2;
 struct V1Streams {
-    uint32_t numSub;   // requested sub-batches (1 = no overlap, 0 = automatic)
-    uint32_t maxSub;   // slots reserved in the stage-event array (= kMaxSubBatches)
-    hipStream_t side[kMaxSubBatches - 1];
-    hipEvent_t fork, stagger[kMaxSubBatches - 1], join[kMaxSubBatches - 1];
+    hipStream_t side[1];
+    hipEvent_t fork, stagger[kSideEvents], join[kSideEvents];
 };
+// stage events of one timed call: block 0 = predictor / Golomb stages, block 1 = finalize + scan + pack
+constexpr uint32_t kEventBlocks = 2;
 // *err = 1 (system scope) unless segFirst[0 .. numSegments] ascends inside [0, numPackets] with no step above maxSeg
 void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint32_t numPackets, uint32_t maxSeg, uint32_t *err,
                            uint32_t *segBad,
                            hipStream_t st);
-// sub-batches actually used for a batch of numSegments segments
-uint32_t v1_sub_batches(uint32_t numSegments, uint32_t requested, uint32_t channels);
 bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt);
-// ev (nullable): (maxSub + 1) blocks of kNumStages + 1 events; block h < maxSub = sub-batch h's predictor /
-// Golomb stages on its own stream, block maxSub = finalize + scan + pack on the caller's stream
+// ev (nullable): kEventBlocks blocks of kNumStages + 1 events
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
                             const V1Buffers &vb, const V1Streams &vs, uint32_t numPackets, uint32_t maxSegPackets,
                             hipStream_t st, hipEvent_t *ev);
@@ -196,8 +182,7 @@ struct DecodeArgs {
     DecRec *recs;       // [maxElems][numPackets]
     const uint32_t *gate = nullptr;  // lane decoder as a fallback: its kernels do nothing unless *gate != 0
     HandoffCtl ho;
-    int32_t optFused = -1, optWide = 1, optPair = 1, optLocal = 1;  // AlacOptions::decFused / decWide / decPair (host-side launch choices)
-    uint32_t optPubMask = 0xffffffffu;   // AlacOptions::decPubMask (-1: 7 with workgroup-local followers, 31 otherwise)
+    int32_t optFused = -1, optPair = 1;  // AlacOptions::decFused / decPair (host-side launch choices)
     int32_t *resid;  // [ch][frameSize][numPackets] residuals, then samples, in place
     uint8_t *pcmOut;
     uint32_t *numSamplesOut;

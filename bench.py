@@ -323,6 +323,9 @@ def encode_roofline(fmt, B, total_bytes, stage_ms, thru_hint):
     ttab, tnote = load_counters("hbm_traffic.json", key)
     traffic = ttab.get(dom) if ttab else None
     traffic_step = sum(v for v in ttab.values() if isinstance(v, (int, float))) if ttab else None
+    upper = (ttab or {}).get("_upper_bound") or {}
+    traffic_upper = upper.get(dom) if upper else None
+    traffic_step_upper = sum(upper.values()) if upper else None
     # the bound that actually holds: VALU issue.  Wave-instructions per pass (PMC instruction mix of the same command)
     issue = None
     itab, inote = load_counters("instruction_mix.json", key)
@@ -344,6 +347,11 @@ def encode_roofline(fmt, B, total_bytes, stage_ms, thru_hint):
     roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tnote,
             "traffic_whole_step": traffic_step,
+            "traffic_upper_bound": traffic_upper, "traffic_whole_step_upper_bound": traffic_step_upper,
+            "traffic_how": "reads = FETCH_SIZE x the factor calibrated on the kernel's read shape (2.0 coalesced streams, 1.466 the "
+                           "predictor's staging, 1.0 one-lane-per-row loads; tools/fetch_calibrate.hip as MI355X_MICROARCH.md asks "
+                           "for access shapes other than wide streaming reads), writes = WRITE_SIZE; *_upper_bound = 2 x FETCH_SIZE "
+                           "+ WRITE_SIZE whatever the shape (what rounds 1-3 reported)",
             "kernel": dom, "kernel_symbol": sym, "longest_stage": longest,
             "kernel_ms": round(ms_dom, 4), "launches_per_step": n_dom,
             "algorithmic_bytes_per_launch": algo_bytes,
@@ -351,7 +359,8 @@ def encode_roofline(fmt, B, total_bytes, stage_ms, thru_hint):
             "whole_step": {"algorithmic_bytes": compulsory_step, "gpu_ms": round(gpu_ms, 4),
                            "achieved": round(compulsory_step / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
                            "frac": round(compulsory_step / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if gpu_ms > 0 else None,
-                           "traffic_over_algorithmic": round(traffic_step / compulsory_step, 2) if traffic_step else None},
+                           "traffic_over_algorithmic": round(traffic_step / compulsory_step, 2) if traffic_step else None,
+                           "traffic_upper_bound_over_algorithmic": round(traffic_step_upper / compulsory_step, 2) if traffic_step_upper else None},
             "issue": issue,
             "note": "dominant stage by measured time (HIP events on the library's stream inside this run); algorithmic bytes = "
                     "SURVEY §8(d) compulsory bytes (PCM in + packet bits out for a fused launch), hand-off planes counted "
@@ -385,11 +394,13 @@ def decode_leg(torch, ctx, fmt, B, stream, offsets, d_pcm, reps):
     ach = comp / (ev_ms * 1e-3) / 1e9
     ttab, tnote = load_counters("hbm_traffic.json", f"decode_{fmt.bit_depth}bit_stereo_{B}")
     tstep = sum(v for v in ttab.values() if isinstance(v, (int, float))) if ttab else None
+    tupper = sum(((ttab or {}).get("_upper_bound") or {}).values()) or None
     return {"ms_per_step": round(ddt * 1e3, 4), "value": round(B * fmt.frame_size / ddt / 1e6, 1),
             "unit": "Msamples/s", "steps": reps,
             "round_trip_exact": bool(torch.equal(d_out, d_pcm)) and int(d_st.abs().sum()) == 0,
             "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tstep, "traffic_source": tnote,
+                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": tstep, "traffic_upper_bound": tupper,
+                         "traffic_source": tnote,
                          "kernel": "whole decode pass (k_dec_stage, k_dec_header, then up to 65 536 chains k_dec_fused_wg [entropy wave + "
                                    "its three predictor waves per workgroup], above that k_dec_raw, k_dec_entropy_wide, k_dec_unpc_wide "
                                    "[pairs write the PCM]; k_dec_unpc, k_dec_unmix for what is left)",
@@ -722,7 +733,12 @@ def rank_main_body(args, json_fd):
                 out["cpu_reference_stages"] = ref_stages
             out["bit_exact_vs_cpu"] = exact
             out["bit_exact_packets"] = n
-            out["speedup_vs_cpu_1thread"] = round(value / base["value"], 1)
+            # against the FASTER single-thread CPU figure of this run: the reference's own compiled stages when they travelled
+            denom = max(base["value"], ref_stages["value"] if ref_stages else 0.0)
+            out["speedup_vs_cpu_1thread"] = round(value / denom, 1)
+            out["speedup_vs_cpu_1thread_denominator"] = ("cpu_reference_stages" if ref_stages and ref_stages["value"] >= base["value"]
+                                                         else "cpu_baseline")
+            out["speedup_vs_cpu_port_1thread"] = round(value / base["value"], 1)
             out["cpu_all_cores"] = cpu_all_cores(fmt)
         if world == 1 and not args.no_legs and args.packets == 0 and args.bit_depth == 16:
             del bufs, last

@@ -66,21 +66,26 @@ void alac_hip_destroy(alac_hip_ctx *ctx);
 int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
 /* Code-path switches of ONE context (no reference counterpart: the reference has a single path).  The library picks a
  * regime per call from the batch shape; a caller can pin one.  The ALAC_HIP_<KEY> environment variables only provide the
- * defaults a context is created with.  value -1 = automatic where the key has an automatic mode.  Keys:
- *   "thru" (-1/0/1)        encode: throughput regime (separate launches, 8 taps per lane, final pass per packet class)
- *   "narrow" (-1/0/1)      encode: four lanes per chain (tiny batches, chained files)
- *   "fused" (0/1)          encode: predictor || entropy coder as one producer/consumer launch (latency regime)
- *   "idlefast", "wide81" (-1/0/1), "split_coder", "overlap_pos", "pubfence" (0/1), "subbatch" (0..8), "persist" (-1/0/1)
- *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels
- *   "dec_fused" (-1/0/1), "dec_wide" (0/1), "dec_pair" (0/1), "dec_local" (0/1), "dec_pubmask" (-1 = auto)   decode launch shape
- *   "class_fused", "search_fused" (0/1), "thru_wg4" (0/1)   throughput regime: predictor + coder of a chain in one lane (final
- *                          pass / searches), four waves per workgroup
- *   "fold" (bit mask), "count_walk" (0/1), "init_state" (0/1), "lds_pad"   latency regime: launches folded into their
- *                          neighbours, the mixRes count as a walking consumer, workspace rows always initialised, LDS padding
+ * defaults a context is created with.  Keys (value range; -1 = automatic):
+ *   "thru" (-1/0/1)        encode: throughput regime — one kernel per stage, a chain's predictor and coder in one lane,
+ *                          final pass per packet class; automatic above 65 536 chains
+ *   "narrow" (-1/0/1)      encode: four lanes per chain (tiny batches, chained files); automatic up to 4096 chains
+ *   "fused" (0/1)          encode: predictor || entropy coder as producer/consumer launches (latency and tiny regimes);
+ *                          0 = one plain kernel per stage ("stagewise": also what frames above 524 287 samples get)
+ *   "fold" (0/1)           latency regime: numU / numV / escape decision and the packet sizes inside the final launch
+ *   "split_coder" (0/1)    tiny regime: the final coder of a chain on two waves
+ *   "overlap_pos" (0/1)    chained tiny batches: packet position p + 1's search beside position p's final pass
  *   "fast_mode" (0/1)      ALACEncoder::SetFastMode: the search-free stereo path (EncodeStereoFast)
+ *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels (a second, structurally different
+ *                          implementation kept for differential testing)
+ *   "dec_fused" (-1/0/1)   decode: entropy wave + its predictor waves in one launch; automatic up to 65 536 chains
+ *   "dec_pair" (0/1)       decode, separate launches, 16-bit stereo: the two predictor lanes of a packet un-mix and write the PCM
  *   "stage_taps" (0/1)     alac_hip_pc_block: tap-parallel kernel for 5..30 taps
- *   "debug_lose_handoff" (0/1)  test switch: producers of the in-launch hand-offs never publish
- * Every setting produces the same bytes; only the kernels that run differ.  Unknown key -> kALAC_ParamError. */
+ *   "debug_waves" (0/1)    diagnostics, see alac_hip_debug_waves_offset
+ *   "debug_lose_handoff" (0/1)  TEST switch, the one key that invalidates results by design: producers of the in-launch
+ *                          hand-offs never publish, so every call fails with kALAC_MemFullError at the next synchronize
+ * Every other setting produces the same bytes; only the kernels that run differ.  Unknown key or a value outside the
+ * key's range -> kALAC_ParamError. */
 int32_t alac_hip_set_option(alac_hip_ctx *ctx, const char *key, int32_t value);
 int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value);
 /* Diagnostics: with option "debug_waves" = 1 the fused final launch of alac_hip_encode leaves 8 dwords per workgroup at this
@@ -88,8 +93,9 @@ int32_t alac_hip_get_option(alac_hip_ctx *ctx, const char *key, int32_t *value);
  * wave ran (tools/wave_map.py).  Batches above 4096 chains only (below, the words are the row-ready flags of chained files). */
 uint64_t alac_hip_debug_waves_offset(const alac_hip_format *fmt, uint32_t num_packets, uint32_t num_segments);
 /* The encode regime this context would pick for a batch of num_segments independent segments of this format (a static
- * string): "throughput" (separate launches, 64 chains per wave), "latency" (producer/consumer launches, two lanes per
- * chain), "tiny" (four lanes per chain: chained files) or "lane" (first-generation kernel).  For reporting. */
+ * string, from the launcher's own predicates): "throughput" (separate launches, 64 chains per wave), "latency"
+ * (producer/consumer launches, two lanes per chain), "tiny" (four lanes per chain: chained files), "stagewise" (option
+ * "fused" = 0) or "lane" (first-generation kernel).  For reporting. */
 const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt, uint32_t num_segments);
 /* Text of the last HIP/parameter error on this context ("" if none). */
 const char *alac_hip_last_error(const alac_hip_ctx *ctx);

@@ -1011,8 +1011,9 @@ int32_t oalac_encode_packet(oalac_encoder *e, const uint8_t *pcm, uint32_t numSa
             oalac_put_bits(out, &pos, tag, 3);
             if (tag == 1) {
                 oalac_put_bits(out, &pos, stereoTag++, 4);
-                status = e->fastMode ? encode_stereo_fast(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples)
-                                     : encode_stereo(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples);
+                /* mFastMode is consulted in the mChannelsPerFrame == 2 branch only (ALACEncoder.cu:998-1001): the element
+                 * loop of a > 2-channel stream always searches */
+                status = encode_stereo(e, out, &pos, pcm + (size_t)ci * bps, e->numChannels, ci, numSamples);
                 ci += 2;
             } else {
                 oalac_put_bits(out, &pos, monoTag++, 4);

@@ -15,7 +15,7 @@ def _check(gpu_ctx, oracle, fmt, nseg, per, sample_segments, expect_regime="tiny
     import torch
     n = nseg * per
     # with default options these shapes run in the tiny-batch regime; tests/test_gpu_variants.py runs them in the others
-    assert gpu_ctx.regime(fmt, nseg) in (expect_regime, "latency", "throughput", "lane")
+    assert gpu_ctx.regime(fmt, nseg) in (expect_regime, "latency", "throughput", "lane", "stagewise")
     pcm = alac_amd.synth_pcm(3, n, fmt)
     seg_first = torch.arange(0, n + 1, per, dtype=torch.int32).cuda()
     state = torch.zeros((nseg, 64), dtype=torch.int16).cuda()

@@ -216,8 +216,8 @@ def test_packer_spans_and_seams_every_depth(gpu_ctx, oracle, depth, channels, fr
     assert escapes >= 4  # the noise packets of useful length really took the uncompressed path
 
 
-@pytest.mark.parametrize("opts", [{}, {"thru": 1}, {"narrow": 0}, {"thru": 1, "search_fused": 0, "class_fused": 0}],
-                         ids=["default", "throughput", "two-lane", "throughput-separate"])
+@pytest.mark.parametrize("opts", [{}, {"thru": 1}, {"narrow": 0}, {"fused": 0}],
+                         ids=["default", "throughput", "two-lane", "stagewise"])
 def test_tiny_frames_ending_in_zero_runs(gpu_ctx, oracle, opts):
     """Frames so short that the numUV count has no stale tail (N / 8 <= max(N / 32, numUV + 1), i.e. N < 80) and whose residuals
     end in zeros, so that every bit count ends with an OPEN zero run that the end of the stream has to close (ag_enc.c:351).

@@ -7,21 +7,31 @@ import alac_amd
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ["thru", "idlefast", "wide81", "narrow", "split_coder", "pubfence", "overlap_pos", "fused", "subbatch",
-        "encoder_lane", "decoder_lane", "dec_fused", "dec_wide", "dec_pair", "dec_local", "dec_pubmask", "stage_taps",
-        "persist", "class_fused", "search_fused", "fold", "thru_wg4", "fast_mode", "count_walk", "init_state"]
+KEYS = {"thru": (-1, 1), "narrow": (-1, 1), "split_coder": (0, 1), "overlap_pos": (0, 1), "fused": (0, 1), "fold": (0, 1),
+        "fast_mode": (0, 1), "encoder_lane": (0, 1), "decoder_lane": (0, 1), "dec_fused": (-1, 1), "dec_pair": (0, 1),
+        "stage_taps": (0, 1), "debug_lose_handoff": (0, 1), "debug_waves": (0, 1)}
+REMOVED = ["idlefast", "wide81", "pubfence", "subbatch", "persist", "class_fused", "search_fused", "thru_wg4", "lds_pad",
+           "count_walk", "init_state", "dec_wide", "dec_local", "dec_pubmask"]  # measured and rejected variants, gone in round 4
 
 
 def test_every_documented_key_round_trips_and_is_documented():
     import os
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "alac_hip.h")).read()
     ctx = alac_amd.Context(0)
-    for k in KEYS:
+    for k, (lo, hi) in KEYS.items():
         old = ctx.get_option(k)
-        for v in (0, 1, old):
+        for v in list(range(lo, hi + 1)) + [old]:
             ctx.set_option(k, v)
             assert ctx.get_option(k) == v, k
+        for v in (lo - 1, hi + 1, 1 << 20, -(1 << 20)):  # values outside the documented range are refused
+            with pytest.raises(Exception):
+                ctx.set_option(k, v)
+            assert ctx.get_option(k) == old, k
         assert f'"{k}"' in header, f"{k} is not listed in include/alac_hip.h"
+    for k in REMOVED:
+        with pytest.raises(Exception):
+            ctx.set_option(k, 0)
+        assert f'"{k}"' not in header
 
 
 def test_unknown_key_is_a_param_error():
@@ -44,3 +54,5 @@ def test_options_belong_to_one_context_and_steer_the_regime():
     with b.options(encoder_lane=1):
         assert b.regime(fmt, 10000) == "lane"
     assert b.regime(fmt, 10000) == "latency"
+    with b.options(fused=0):  # the launcher's predicate: narrow only counts while the launches are fused
+        assert b.regime(fmt, 100) == "stagewise" and b.regime(fmt, 10000) == "stagewise" and b.regime(fmt, 125000) == "throughput"

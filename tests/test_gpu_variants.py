@@ -1,6 +1,6 @@
 """The alternative code paths behind the same C-ABI must pass the same parity tests: the first-generation
-lane-per-chain encoder / decoder (options encoder_lane / decoder_lane), the un-fused launches (fused = 0, dec_fused = 0,
-idlefast = 0), and the regimes the batch size normally selects: the small batches of the parity files run on the
+lane-per-chain encoder / decoder (options encoder_lane / decoder_lane), the un-fused launches (fused = 0, dec_fused = 0),
+and the regimes the batch size normally selects: the small batches of the parity files run on the
 four-lanes-per-chain mapping by default, so narrow = 0 puts them on the two-lane kernels of the 10 000-packet benchmark
 and thru = 1 on the throughput regime's launches (class compaction, 8-taps-in-a-lane search, lazy word stores; DESIGN.md
 4.0).  The switches are per-context options (alac_hip_set_option), so every variant runs IN THIS PROCESS: a nested pytest
@@ -11,25 +11,18 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["tests/test_gpu_encode.py", "tests/test_gpu_decode.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_multichannel.py",
-         "tests/test_gpu_wholefile.py", "tests/test_gpu_chained.py"]
+FILES = ["tests/test_gpu_encode.py", "tests/test_gpu_decode.py", "tests/test_gpu_foreign.py", "tests/test_gpu_fuzz.py",
+         "tests/test_gpu_multichannel.py", "tests/test_gpu_wholefile.py", "tests/test_gpu_chained.py"]
 
 VARIANTS = {
     "first-generation": {"encoder_lane": 1, "decoder_lane": 1},
-    "unfused": {"fused": 0, "dec_fused": 0},
-    "idle-checked": {"idlefast": 0},
-    "release-fence": {"pubfence": 1},
+    "stagewise": {"fused": 0, "dec_fused": 0},
     "two-lane-latency-regime": {"narrow": 0},
     "two-lane-latency-regime-unfolded": {"narrow": 0, "fold": 0},
-    "throughput-regime-separate-stages": {"thru": 1, "class_fused": 0, "search_fused": 0},
     "throughput-regime": {"thru": 1},
-    "throughput-regime-sub-batches": {"thru": 1, "subbatch": 2},
     "positions-not-overlapped": {"overlap_pos": 0},
-    "unfused-two-lane-decode-predictor": {"dec_fused": 0, "dec_wide": 0},
     "unfused-decode-chains-not-paired": {"dec_fused": 0, "dec_pair": 0},
-    "fused-decode-followers-anywhere": {"dec_local": 0},
     "tiny-batch-coder-not-split": {"split_coder": 0},
-    "chained-not-persistent": {"persist": 0},
 }
 
 

@@ -13,7 +13,17 @@
       -> profiles/instruction_mix.json[KEY]        wave-instructions per pass: total, per stage, per kernel
 
 Corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: counter unit is KiB; on gfx950
-FETCH_SIZE counts 128-B requests as 64 B, so reads = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
+FETCH_SIZE tallies a 128-B request as 64 B, so a WIDE COALESCED streaming read is 2 * FETCH_SIZE * 1024 and "other access
+widths are uncalibrated: calibrate on a known byte count in your own access pattern".  tools/fetch_calibrate.hip does that
+for this library's read shapes (profiles/r04/fetch_calibration.json, known bytes / counter bytes):
+    stream16      64 lanes x 16 B consecutive                                  2.000   (packer, k_dec_stage, un-mix, planes)
+    rows192       predictor staging: 12 lanes cover 192 contiguous bytes of one packet row, rows 16 KB apart,
+                  64 of every 192 bytes re-read one tile later                 1.466   (1.713 without the re-read)
+    lane_rows16   one lane = one row, 16-B loads                               0.444   (the counter is EXACT here: 64-B
+                  requests, and each line is fetched 2.25 times before the lane has used it up)
+so reads = FACTOR[kernel's dominant shape] * FETCH_SIZE * 1024 with factor 2.0 / 1.466 / 1.0 (READ_FACTOR below); every
+table also carries the blanket 2 x figure rounds 1-3 reported (`_upper_bound`) and the uncorrected counter (`_counter_raw`).
+WRITE_SIZE is exact for 16-B stores (calibrated 1.000); scattered 4-byte stores are counted at 64 B per request (0.113).
 Every table is stored with the fingerprint of the kernel sources it was collected on (alac_amd.source_fingerprint(),
 computed ON THE GPU BOX by profile_round.sh): bench.py ignores a table whose fingerprint is not its own.
 """
@@ -40,6 +50,21 @@ STAGE_OF = [
     ("k_chain_", "lms_final"),
     ("k_finalize", "finalize_scan"), ("k_scan_sizes", "finalize_scan"), ("k_pack", "pack"),
 ]
+
+
+# dominant READ shape of a kernel -> factor on FETCH_SIZE (module docstring); default 2.0 (coalesced)
+READ_FACTOR = [
+    ("k_search1_lane", 1.466), ("k_search2_lane", 1.466), ("k_class_final", 1.466), ("k_final_fused", 1.466),
+    ("k_search1_fused", 1.466), ("k_lms_search", 1.466), ("k_lms_final", 1.466),
+    ("k_dec_entropy_wide", 1.0), ("k_dec_unpc_wide", 1.0), ("k_dec_fused_wg", 1.0), ("k_dec_unpc", 1.0),
+]
+
+
+def read_factor(k):
+    for sub, f in READ_FACTOR:
+        if sub in k:
+            return f
+    return 2.0
 
 
 def short_name(k):
@@ -90,33 +115,46 @@ def main():
     if fp is None:
         with open(os.path.join(a.dir, "fingerprint.txt")) as f:
             fp = f.read().strip()
-    note = {"_note": "bytes (resp. wave-instructions) per PASS = sum over every launch in the profiled run / passes; reads = 2 * "
-                     "FETCH_SIZE KiB * 1024 (gfx950), writes = WRITE_SIZE KiB * 1024; tools/pmc_tables.py"}
+    note = {"_note": "bytes (resp. wave-instructions) per PASS = sum over every launch in the profiled run / passes; reads = "
+                     "READ_FACTOR(kernel) * FETCH_SIZE KiB * 1024 with the factor calibrated on the kernel's dominant read shape "
+                     "(tools/fetch_calibrate.hip: 2.0 coalesced, 1.466 predictor staging, 1.0 one-lane-per-row), writes = "
+                     "WRITE_SIZE KiB * 1024; _upper_bound = the blanket 2 x FETCH_SIZE + WRITE_SIZE of rounds 1-3; tools/pmc_tables.py"}
     fpath, wpath = os.path.join(a.dir, "pmc_fetch_size.csv"), os.path.join(a.dir, "pmc_write_size.csv")
     if os.path.exists(fpath) and os.path.exists(wpath):
         rd, _ = sums(fpath)
         wr, nl = sums(wpath)
         enc, dec, raw = defaultdict(float), defaultdict(float), {}
+        encU, decU = defaultdict(float), defaultdict(float)
         for k in sorted(set(rd) | set(wr)):
-            b = 2.0 * rd[k].get("FETCH_SIZE", 0.0) * 1024.0 + wr[k].get("WRITE_SIZE", 0.0) * 1024.0
+            F, W = rd[k].get("FETCH_SIZE", 0.0) * 1024.0, wr[k].get("WRITE_SIZE", 0.0) * 1024.0
+            f = read_factor(k)
+            b, bu = f * F + W, 2.0 * F + W
             st = stage_of(k)
             if st:
                 enc[st] += b / a.passes
-                raw[k] = {"bytes_per_pass": int(b / a.passes), "launches_per_pass": round(nl.get(k, 0) / a.passes, 2)}
+                encU[st] += bu / a.passes
+                raw[k] = {"bytes_per_pass": int(b / a.passes), "launches_per_pass": round(nl.get(k, 0) / a.passes, 2),
+                          "fetch_counter_bytes": int(F / a.passes), "write_bytes": int(W / a.passes), "read_factor": f,
+                          "upper_bound_bytes": int(bu / a.passes)}
             elif "k_dec" in k and a.decode_passes:
                 dec[k.split("<")[0]] += b / a.decode_passes
+                decU[k.split("<")[0]] += bu / a.decode_passes
         t = {k: int(v) for k, v in enc.items()}
         t["_per_kernel"] = raw
+        t["_upper_bound"] = {k: int(v) for k, v in encU.items()}
         t.update(note)
         update(os.path.join(ROOT, "profiles", "hbm_traffic.json"), a.key, t, fp)
-        print("traffic", a.key, {k: v for k, v in t.items() if not k.startswith("_")})
+        print("traffic", a.key, {k: v for k, v in t.items() if not k.startswith("_")}, "upper", t["_upper_bound"])
         if dec:
             # the plane clears / memsets of the decode pass (fillBufferAligned) cannot be told from the encoder's small flag
             # clears by name; the encoder's are a few KB per pass, so they are all charged to the decode pass
             for k in rd:
                 if "fillBuffer" in k and a.decode_passes:
-                    dec["fillBufferAligned"] += (2.0 * rd[k].get("FETCH_SIZE", 0.0) + wr[k].get("WRITE_SIZE", 0.0)) * 1024.0 / a.decode_passes
+                    v = (2.0 * rd[k].get("FETCH_SIZE", 0.0) + wr[k].get("WRITE_SIZE", 0.0)) * 1024.0 / a.decode_passes
+                    dec["fillBufferAligned"] += v
+                    decU["fillBufferAligned"] += v
             d = {k: int(v) for k, v in dec.items()}
+            d["_upper_bound"] = {k: int(v) for k, v in decU.items()}
             d.update(note)
             update(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "decode_" + a.key, d, fp)
             print("traffic decode_" + a.key, {k: v for k, v in d.items() if not k.startswith("_")})
