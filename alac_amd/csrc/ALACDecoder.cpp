@@ -27,7 +27,7 @@ uint32_t peek_num_samples(const uint8_t *p, size_t n, uint32_t frameLength)
 }
 }  // namespace
 
-ALACDecoder::ALACDecoder() : mCtx(nullptr), mLastStatus(0) { memset(&mConfig, 0, sizeof(mConfig)); }
+ALACDecoder::ALACDecoder() : mCtx(nullptr), mDevice(-1), mLastStatus(0) { memset(&mConfig, 0, sizeof(mConfig)); }
 
 ALACDecoder::~ALACDecoder()
 {
@@ -58,7 +58,7 @@ int32_t ALACDecoder::Init(void *inMagicCookie, uint32_t inMagicCookieSize, int /
     mConfig.sampleRate = fmt.sample_rate;
     if (!mCtx) {
         const char *dev = getenv("ALAC_HIP_DEVICE");
-        if (alac_hip_create(&mCtx, dev ? atoi(dev) : 0, nullptr) != ALAC_HIP_noErr) return kALAC_MemFullError;
+        if (alac_hip_create(&mCtx, mDevice >= 0 ? mDevice : (dev ? atoi(dev) : 0), nullptr) != ALAC_HIP_noErr) return kALAC_MemFullError;
     }
     mQueued.clear();
     mQueuedSizes.clear();

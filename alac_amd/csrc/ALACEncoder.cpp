@@ -19,7 +19,7 @@ inline uint16_t be16(uint16_t v) { return (uint16_t)((v << 8) | (v >> 8)); }
 ALACEncoder::ALACEncoder()
     : mBitDepth(0), mFastMode(false), mTotalBytesGenerated(0), mAvgBitRate(0), mMaxFrameBytes(0),
       mFrameSize(kALACDefaultFrameSize), mMaxOutputBytes(0), mNumChannels(0), mOutputSampleRate(0), mCtx(nullptr),
-      mStateValid(false), mLastStatus(0)
+      mDevice(-1), mStateValid(false), mLastStatus(0)
 {
     memset(mState, 0, sizeof(mState));
 }
@@ -46,7 +46,7 @@ int32_t ALACEncoder::InitializeEncoder(AudioFormatDescription theOutputFormat, i
     mMaxOutputBytes = mFrameSize * mNumChannels * ((10 + 32) / 8) + 1;        // :1489
     if (!mCtx) {
         const char *dev = getenv("ALAC_HIP_DEVICE");
-        int32_t rc = alac_hip_create(&mCtx, dev ? atoi(dev) : 0, nullptr);
+        int32_t rc = alac_hip_create(&mCtx, mDevice >= 0 ? mDevice : (dev ? atoi(dev) : 0), nullptr);
         if (rc != ALAC_HIP_noErr) return kALAC_MemFullError;
     }
     mStateValid = false;  // every row = init_coefs (:1524-1531)

@@ -315,7 +315,11 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     // shift-off bytes, 32-bit mono: the generic predictor's job)
     const bool fastShape = (A.frameSize & 7) == 0 && R.numSamples >= 16 && haveElement && !R.escape && chanBits <= kFastChanBits;
     const bool ok0 = good && fastShape && okc[0], ok1 = good && fastShape && R.elementChannels == 2 && okc[1];
-    const bool pair = stereo16 && V.lists && V.pairs && ok0 && ok1;
+    // pairs: 16-bit stereo, and (round 4) 20- / 24-bit stereo with at most one shifted-off byte per sample — what every encoder
+    // emits for that material (unpc_pair_body<T, DEPTH> re-attaches the bytes and packs the 3-byte samples itself)
+    const bool pairDepth = stereo16 || ((A.bitDepth == 24 || A.bitDepth == 20) && A.numChannels == 2 && V.outChannels == 2 &&
+                                        V.elemBit == nullptr && R.bytesShifted <= 1);
+    const bool pair = pairDepth && V.lists && V.pairs && ok0 && ok1;
     const bool rawP = good && haveElement && R.escape != 0;
     const bool rawDirect = rawP && stereo16 && R.elementChannels == 2;
     if (live) rec->pad2 = (pair || rawDirect) ? 1u : 0u;
@@ -1140,7 +1144,7 @@ __device__ __forceinline__ int32_t lms_step_dec_pair(int32_t (&a)[T], int32_t (&
     return out;
 }
 
-template <int T>
+template <int T, int DEPTH = 16>
 __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t block, uint32_t count)
 {
     const DecodeArgs &A = V.d;
@@ -1163,12 +1167,89 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t bloc
     const bool isU = ch == 0;
     int32_t *row = V.plane + ((uint64_t)p * 2 + ch) * A.frameSize;
     uint32_t *pcm = (uint32_t *)(A.pcmOut + (uint64_t)p * A.frameSize * 4);  // one word per frame: L | R << 16
+    // 20 / 24 bits: six bytes per frame; the shifted-off bytes (one per sample: k_dec_header lists no other packet as a pair)
+    // sit in the staged stream, two per frame from bit shiftPos on (codec/ALACDecoder.cu:905-915, gpu_unmix24 :282-338)
+    uint8_t *pcm3 = A.pcmOut + (uint64_t)p * A.frameSize * 6;
+    const bool shifted = DEPTH == 24 && active && rec->bytesShifted != 0;
+    const uint64_t pktOff = active ? A.offsets[p] : 0;
+    const uint64_t sWordBase = pktOff >> 2, sBit0 = (pktOff & 3) * 8 + (active ? rec->shiftPos : 0);
 
     // K outputs of each lane of a pair -> K frames: the U lane takes the first K / 2 frames, the V lane the rest; one DPP
     // exchange per frame hands each lane the sample of the other channel it needs (gpu_unmix16, codec/ALACDecoder.cu:193-223)
     typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
     auto emit = [&](auto &o, auto kc, uint32_t jb) {
         constexpr int K = decltype(kc)::value;
+        if constexpr (DEPTH != 16) {
+            // this lane's K / 2 frames: their shift bytes are K bytes of the stream = K / 4 words at an arbitrary bit offset
+            const uint32_t f0 = jb + (isU ? 0u : (uint32_t)(K / 2));
+            uint32_t sw[K / 4 + 1];
+            uint32_t ssh = 0;
+            if (shifted) {
+                const uint64_t b = sBit0 + (uint64_t)f0 * 16;
+                const uint64_t i0 = min(sWordBase + (b >> 5), V.capWords - (uint64_t)(K / 4 + 2));  // status-0 packets lie inside the stage
+                ssh = (uint32_t)(b & 31);
+#pragma unroll
+                for (int q = 0; q <= K / 4; q++) sw[q] = V.words[i0 + q];
+            }
+            uint32_t fld[K];  // L0 R0 L1 R1 ... as 24-bit little-endian fields
+#pragma unroll
+            for (int k = 0; k < K / 2; k++) {
+                const int32_t give = isU ? o[k + K / 2] : o[k];
+                const int32_t recv = dpp_xor1(give);
+                const int32_t mine = isU ? o[k] : o[k + K / 2];
+                const int32_t uu = isU ? mine : recv, vv = isU ? recv : mine;
+                int32_t l = uu + ((vv - ((mixRes * vv) >> mixBits)) & mixMask);
+                int32_t r = mixRes != 0 ? l - vv : vv;
+                if constexpr (DEPTH == 24) {
+                    if (shifted) {
+                        // frame k's two bytes = bits [16 k, 16 k + 16) of the funnel-shifted words
+                        const uint32_t wq = (uint32_t)(k >> 1);
+                        const uint32_t x32 = ssh ? (sw[wq] << ssh) | (sw[wq + 1] >> (32 - ssh)) : sw[wq];
+                        const uint32_t xx = (k & 1) ? (x32 & 0xffffu) : (x32 >> 16);
+                        l = (int32_t)(((uint32_t)l << 8) | (xx >> 8));
+                        r = (int32_t)(((uint32_t)r << 8) | (xx & 0xffu));
+                    }
+                } else {
+                    l = (int32_t)((uint32_t)l << 4);  // 20 bits, left-justified in three bytes (gpu_unmix20 :225-280)
+                    r = (int32_t)((uint32_t)r << 4);
+                }
+                fld[2 * k] = (uint32_t)l & 0xffffffu;
+                fld[2 * k + 1] = (uint32_t)r & 0xffffffu;
+            }
+            uint8_t *dst = pcm3 + (uint64_t)f0 * 6;
+            if (active && f0 + (uint32_t)(K / 2) <= n) {
+                // four 3-byte fields make three words; K fields = 3 K / 4 words = 3 K / 16 sixteen-byte stores
+                typedef uint32_t U4s __attribute__((ext_vector_type(4), aligned(4)));
+                uint32_t d[3 * K / 4];
+#pragma unroll
+                for (int g = 0; g < K / 4; g++) {
+                    const uint32_t a0 = fld[4 * g], a1 = fld[4 * g + 1], a2 = fld[4 * g + 2], a3 = fld[4 * g + 3];
+                    d[3 * g] = a0 | (a1 << 24);
+                    d[3 * g + 1] = (a1 >> 8) | (a2 << 16);
+                    d[3 * g + 2] = (a2 >> 16) | (a3 << 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 3 * K / 16; q++) {
+                    const U4s t4 = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+                    *(U4s *)(dst + 16 * q) = t4;
+                }
+            } else if (active) {
+                // the last frames of a short packet
+#pragma unroll
+                for (int k = 0; k < K / 2; k++) {
+                    if (f0 + (uint32_t)k < n) {
+#pragma unroll
+                        for (int c2 = 0; c2 < 2; c2++) {
+                            const uint32_t v3 = fld[2 * k + c2];
+                            dst[6 * k + 3 * c2] = (uint8_t)v3;
+                            dst[6 * k + 3 * c2 + 1] = (uint8_t)(v3 >> 8);
+                            dst[6 * k + 3 * c2 + 2] = (uint8_t)(v3 >> 16);
+                        }
+                    }
+                }
+            }
+            return;
+        }
         uint32_t word[K / 2];
 #pragma unroll
         for (int k = 0; k < K / 2; k++) {
@@ -1274,17 +1355,20 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t bloc
 // packets) and was as slow as its own serial chain: 1.65 + 1.29 ms.
 // (pair mode: class-B pairs, 8-tap chains, class-A pairs, 4-tap chains)
 // Four waves to a workgroup (one per SIMD of its CU), consecutive roles: see k_dec_entropy_wide.
+// DEPTH: what the pairs write (16: one word per frame; 20 / 24: six bytes per frame) — one instantiation per output format,
+// so that a launch carries four loop bodies, not eight (they share the CU's instruction cache)
+template <int DEPTH>
 __global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_unpc_wide(DecV1Args V)
 {
     const uint32_t *cnt = dec_lists(V).cnt;
     const uint32_t c4 = cnt[0], c8 = cnt[1], pA = cnt[2], pB = cnt[3];
     const uint32_t nbB = (pB + 31u) / 32u, nb8 = (c8 + 63u) / 64u, nbA = (pA + 31u) / 32u;
     uint32_t b = blockIdx.x * (uint32_t)kEntWavesPerWg + (threadIdx.x >> 6);
-    if (b < nbB) return unpc_pair_body<8>(V, b, pB);
+    if (b < nbB) return unpc_pair_body<8, DEPTH>(V, b, pB);
     b -= nbB;
     if (b < nb8) return unpc_wide_body<8>(V, b, c8);
     b -= nb8;
-    if (b < nbA) return unpc_pair_body<4>(V, b, pA);
+    if (b < nbA) return unpc_pair_body<4, DEPTH>(V, b, pA);
     b -= nbA;
     unpc_wide_body<4>(V, b, c4);
 }
@@ -1591,8 +1675,10 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
         // instructions whose 64 lanes hit 64 different cache lines, which a CU's address path takes one line at a time)
         hipLaunchKernelGGL(k_dec_entropy_wide, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
         // chains sorted by tap count, one lane per chain
-        hipLaunchKernelGGL(k_dec_unpc_wide, dim3(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg),
-                           dim3(64 * kEntWavesPerWg), 0, st, V);
+        const dim3 ugrid(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg), ublock(64 * kEntWavesPerWg);
+        if (da.bitDepth == 24) hipLaunchKernelGGL(k_dec_unpc_wide<24>, ugrid, ublock, 0, st, V);
+        else if (da.bitDepth == 20) hipLaunchKernelGGL(k_dec_unpc_wide<20>, ugrid, ublock, 0, st, V);
+        else hipLaunchKernelGGL(k_dec_unpc_wide<16>, ugrid, ublock, 0, st, V);
     }
     hipLaunchKernelGGL(k_dec_unpc, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, st, V);
     switch (da.bitDepth) {

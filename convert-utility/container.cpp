@@ -3,8 +3,10 @@
  */
 #include "container.h"
 
+#include <cctype>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 
 namespace alacfile {
 
@@ -159,6 +161,11 @@ std::string sniff_input(const Bytes &f, InputInfo &info)
         if (szLow < 4 || sz > avail) sz = avail;  // unknown (-1) or overlong size: take what the file holds
         info.dataSize = sz;
         return "";
+    }
+
+    if (tag_is(&f[4], "ftyp")) {  // ISO base media file (MP4 / M4A): the whole parse is parse_alac_m4a's
+        AlacCafContents c;
+        return parse_alac_m4a(f, info, c);
     }
 
     if (tag_is(&f[0], "RIFF") && tag_is(&f[8], "WAVE")) {
@@ -457,6 +464,333 @@ std::string parse_alac_sample_description(const Bytes &b, Bytes &cookie, uint32_
     if (be32(&b[info + 4]) != kAlac || infoSize < 12 + 24 || info + infoSize > e + entry) return "bad ALAC specific info";
     cookie.assign(b.begin() + info + 12, b.begin() + info + infoSize);
     return "";
+}
+
+// ---------------------------------------------------------------------------------------------
+// ALAC in MP4 / M4A (ISO/IEC 14496-12 boxes around the sample description of ALACMagicCookieDescription.txt:177-216)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// a box under construction: the 4-byte size is patched when it is closed
+struct BoxWriter {
+    Bytes &o;
+    std::vector<size_t> open;
+    explicit BoxWriter(Bytes &out) : o(out) {}
+    void begin(const char *type)
+    {
+        open.push_back(o.size());
+        put_be32(o, 0);
+        put_tag(o, type);
+    }
+    void full(const char *type, uint32_t versionFlags)
+    {
+        begin(type);
+        put_be32(o, versionFlags);
+    }
+    void end()
+    {
+        const size_t at = open.back();
+        open.pop_back();
+        const uint32_t size = (uint32_t)(o.size() - at);
+        o[at] = (uint8_t)(size >> 24);
+        o[at + 1] = (uint8_t)(size >> 16);
+        o[at + 2] = (uint8_t)(size >> 8);
+        o[at + 3] = (uint8_t)size;
+    }
+};
+
+void put_matrix(Bytes &o)
+{
+    const uint32_t m[9] = {0x00010000u, 0, 0, 0, 0x00010000u, 0, 0, 0, 0x40000000u};  // unity
+    for (int i = 0; i < 9; i++) put_be32(o, m[i]);
+}
+
+// the movie box for one ALAC track whose single chunk starts at chunkOffset
+void put_moov(Bytes &o, const AlacM4aParams &p, const Bytes &cookie, const std::vector<uint32_t> &packetBytes, uint64_t chunkOffset,
+              bool wide)
+{
+    BoxWriter w(o);
+    const uint32_t duration = (uint32_t)(p.totalFrames > 0xffffffffull ? 0xffffffffull : p.totalFrames);
+    const uint32_t np = (uint32_t)packetBytes.size();
+    w.begin("moov");
+    w.full("mvhd", 0);
+    put_be32(o, 0);  // creation / modification time
+    put_be32(o, 0);
+    put_be32(o, p.sampleRate);  // timescale: one tick per sample-frame
+    put_be32(o, duration);
+    put_be32(o, 0x00010000u);  // rate 1.0
+    put_be16(o, 0x0100);       // volume 1.0
+    put_zeros(o, 10);
+    put_matrix(o);
+    put_zeros(o, 24);          // pre_defined
+    put_be32(o, 2);            // next track id
+    w.end();
+    w.begin("trak");
+    w.full("tkhd", 7);         // enabled | in movie | in preview
+    put_be32(o, 0);
+    put_be32(o, 0);
+    put_be32(o, 1);            // track id
+    put_be32(o, 0);
+    put_be32(o, duration);
+    put_zeros(o, 8);
+    put_be16(o, 0);            // layer
+    put_be16(o, 0);            // alternate group
+    put_be16(o, 0x0100);       // volume
+    put_be16(o, 0);
+    put_matrix(o);
+    put_be32(o, 0);            // width, height
+    put_be32(o, 0);
+    w.end();
+    w.begin("mdia");
+    w.full("mdhd", 0);
+    put_be32(o, 0);
+    put_be32(o, 0);
+    put_be32(o, p.sampleRate);
+    put_be32(o, duration);
+    put_be16(o, 0x55c4);       // language 'und'
+    put_be16(o, 0);
+    w.end();
+    w.full("hdlr", 0);
+    put_be32(o, 0);
+    put_tag(o, "soun");
+    put_zeros(o, 12);
+    const char name[] = "SoundHandler";
+    o.insert(o.end(), name, name + sizeof(name));  // with the terminating zero
+    w.end();
+    w.begin("minf");
+    w.full("smhd", 0);
+    put_be32(o, 0);            // balance, reserved
+    w.end();
+    w.begin("dinf");
+    w.full("dref", 0);
+    put_be32(o, 1);
+    w.full("url ", 1);         // self-contained
+    w.end();
+    w.end();
+    w.end();
+    w.begin("stbl");
+    {
+        const Bytes stsd = build_alac_sample_description(cookie, p.channels, p.bitDepth, p.sampleRate);
+        o.insert(o.end(), stsd.begin(), stsd.end());
+    }
+    // time to sample: full packets of framesPerPacket, then what totalFrames leaves for the last one
+    w.full("stts", 0);
+    {
+        const uint64_t full = p.framesPerPacket ? p.totalFrames / p.framesPerPacket : 0;
+        const uint32_t rest = p.framesPerPacket ? (uint32_t)(p.totalFrames - full * p.framesPerPacket) : 0;
+        std::vector<std::pair<uint32_t, uint32_t> > runs;
+        const uint32_t nFull = (uint32_t)(full < np ? full : np);
+        if (nFull) runs.push_back(std::make_pair(nFull, p.framesPerPacket));
+        if (np > nFull) runs.push_back(std::make_pair(np - nFull, rest ? rest : p.framesPerPacket));
+        put_be32(o, (uint32_t)runs.size());
+        for (size_t i = 0; i < runs.size(); i++) {
+            put_be32(o, runs[i].first);
+            put_be32(o, runs[i].second);
+        }
+    }
+    w.end();
+    w.full("stsc", 0);         // one chunk with every sample
+    put_be32(o, np ? 1 : 0);
+    if (np) {
+        put_be32(o, 1);
+        put_be32(o, np);
+        put_be32(o, 1);
+    }
+    w.end();
+    w.full("stsz", 0);
+    put_be32(o, 0);            // sizes follow
+    put_be32(o, np);
+    for (uint32_t i = 0; i < np; i++) put_be32(o, packetBytes[i]);
+    w.end();
+    if (wide) {
+        w.full("co64", 0);
+        put_be32(o, np ? 1 : 0);
+        if (np) put_be64(o, chunkOffset);
+    } else {
+        w.full("stco", 0);
+        put_be32(o, np ? 1 : 0);
+        if (np) put_be32(o, (uint32_t)chunkOffset);
+    }
+    w.end();
+    w.end();  // stbl
+    w.end();  // minf
+    w.end();  // mdia
+    w.end();  // trak
+    w.end();  // moov
+}
+
+struct BoxRef {
+    size_t body, end;  // payload range of a box
+    bool ok;
+};
+
+// first child box of `type` inside [from, to)
+BoxRef find_box(const Bytes &f, size_t from, size_t to, const char *type)
+{
+    size_t pos = from;
+    while (pos + 8 <= to) {
+        uint64_t size = be32(&f[pos]);
+        size_t hdr = 8;
+        if (size == 1) {
+            if (pos + 16 > to) break;
+            size = ((uint64_t)be32(&f[pos + 8]) << 32) | be32(&f[pos + 12]);
+            hdr = 16;
+        } else if (size == 0) {
+            size = to - pos;  // "to the end of the file"
+        }
+        if (size < hdr || pos + size > to) break;
+        if (tag_is(&f[pos + 4], type)) {
+            BoxRef r = {pos + hdr, (size_t)(pos + size), true};
+            return r;
+        }
+        pos += (size_t)size;
+    }
+    BoxRef none = {0, 0, false};
+    return none;
+}
+
+}  // namespace
+
+Bytes build_alac_m4a(const AlacM4aParams &p, const Bytes &cookie, const std::vector<uint32_t> &packetBytes, const uint8_t *stream,
+                     uint64_t streamBytes)
+{
+    Bytes head;
+    {
+        BoxWriter w(head);
+        w.begin("ftyp");
+        put_tag(head, "M4A ");
+        put_be32(head, 0);
+        put_tag(head, "M4A ");
+        put_tag(head, "mp42");
+        put_tag(head, "isom");
+        w.end();
+    }
+    // the movie box is laid out twice: its size does not depend on the chunk offset it stores, only on stco / co64
+    Bytes probe;
+    put_moov(probe, p, cookie, packetBytes, 0, false);
+    const bool wide = head.size() + probe.size() + 16 + streamBytes > 0xffffffffull;
+    if (wide) {
+        probe.clear();
+        put_moov(probe, p, cookie, packetBytes, 0, true);
+    }
+    const uint64_t mdatHeader = wide ? 16 : 8;
+    const uint64_t chunkOffset = head.size() + probe.size() + mdatHeader;
+    Bytes o(head);
+    o.reserve((size_t)(chunkOffset + streamBytes));
+    put_moov(o, p, cookie, packetBytes, chunkOffset, wide);
+    if (wide) {
+        put_be32(o, 1);
+        put_tag(o, "mdat");
+        put_be64(o, 16 + streamBytes);
+    } else {
+        put_be32(o, (uint32_t)(8 + streamBytes));
+        put_tag(o, "mdat");
+    }
+    o.insert(o.end(), stream, stream + streamBytes);
+    return o;
+}
+
+std::string parse_alac_m4a(const Bytes &f, InputInfo &info, AlacCafContents &out)
+{
+    memset(&info, 0, sizeof(info));
+    out.cookie.clear();
+    out.packetBytes.clear();
+    out.packetPos.clear();
+    out.dataPos = 0;
+    info.kind = kM4aFile;
+    if (f.size() < 16 || !tag_is(&f[4], "ftyp")) return "not an MP4 / M4A file";
+    const BoxRef moov = find_box(f, 0, f.size(), "moov");
+    if (!moov.ok) return "no moov box";
+    // the first track whose sample description is 'alac'
+    size_t tpos = moov.body;
+    for (;;) {
+        const BoxRef trak = find_box(f, tpos, moov.end, "trak");
+        if (!trak.ok) return "no ALAC track";
+        tpos = trak.end;
+        const BoxRef mdia = find_box(f, trak.body, trak.end, "mdia");
+        if (!mdia.ok) continue;
+        const BoxRef minf = find_box(f, mdia.body, mdia.end, "minf");
+        if (!minf.ok) continue;
+        const BoxRef stbl = find_box(f, minf.body, minf.end, "stbl");
+        if (!stbl.ok) continue;
+        const BoxRef stsd = find_box(f, stbl.body, stbl.end, "stsd");
+        if (!stsd.ok || stsd.end - stsd.body < 16 + 36 || !tag_is(&f[stsd.body + 12], "alac")) continue;
+        // (the parser of the sample description wants the whole box, header included)
+        const Bytes whole(f.begin() + (stsd.body - 8), f.begin() + stsd.end);
+        uint32_t ch = 0, bits = 0, rate16 = 0;
+        const std::string err = parse_alac_sample_description(whole, out.cookie, ch, bits, rate16);
+        if (!err.empty()) return err;
+        const Bytes bare = unwrap_cookie(out.cookie);
+        if (bare.size() < 24) return "bad magic cookie in the sample description";
+        info.isAlac = true;
+        info.channels = bare[9];                       // the cookie decides (ALACSpecificConfig)
+        info.sampleRate = (double)be32(&bare[20]);
+        info.framesPerPacket = be32(&bare[0]);
+        info.alacSourceFlag = bare[5] == 16 ? 1 : bare[5] == 20 ? 2 : bare[5] == 24 ? 3 : bare[5] == 32 ? 4 : 0;
+        (void)ch;
+        (void)bits;
+        (void)rate16;
+        // sample sizes
+        const BoxRef stsz = find_box(f, stbl.body, stbl.end, "stsz");
+        if (!stsz.ok || stsz.end - stsz.body < 12) return "no stsz box";
+        const uint32_t fixed = be32(&f[stsz.body + 4]), count = be32(&f[stsz.body + 8]);
+        if (!fixed && (uint64_t)count * 4 > stsz.end - stsz.body - 12) return "truncated stsz box";
+        std::vector<uint32_t> sizes(count);
+        for (uint32_t i = 0; i < count; i++) sizes[i] = fixed ? fixed : be32(&f[stsz.body + 12 + 4 * (size_t)i]);
+        // chunk offsets
+        std::vector<uint64_t> chunks;
+        const BoxRef stco = find_box(f, stbl.body, stbl.end, "stco");
+        const BoxRef co64 = find_box(f, stbl.body, stbl.end, "co64");
+        if (stco.ok && stco.end - stco.body >= 8) {
+            const uint32_t n = be32(&f[stco.body + 4]);
+            if ((uint64_t)n * 4 > stco.end - stco.body - 8) return "truncated stco box";
+            for (uint32_t i = 0; i < n; i++) chunks.push_back(be32(&f[stco.body + 8 + 4 * (size_t)i]));
+        } else if (co64.ok && co64.end - co64.body >= 8) {
+            const uint32_t n = be32(&f[co64.body + 4]);
+            if ((uint64_t)n * 8 > co64.end - co64.body - 8) return "truncated co64 box";
+            for (uint32_t i = 0; i < n; i++)
+                chunks.push_back(((uint64_t)be32(&f[co64.body + 8 + 8 * (size_t)i]) << 32) | be32(&f[co64.body + 12 + 8 * (size_t)i]));
+        } else if (count) {
+            return "no chunk offset box";
+        }
+        // sample to chunk runs: (first chunk, samples per chunk, description index), 1-based
+        const BoxRef stsc = find_box(f, stbl.body, stbl.end, "stsc");
+        if (!stsc.ok || stsc.end - stsc.body < 8) return "no stsc box";
+        const uint32_t runs = be32(&f[stsc.body + 4]);
+        if ((uint64_t)runs * 12 > stsc.end - stsc.body - 8) return "truncated stsc box";
+        uint32_t sample = 0;
+        for (uint32_t r = 0; r < runs && sample < count; r++) {
+            const uint8_t *e = &f[stsc.body + 8 + 12 * (size_t)r];
+            const uint32_t first = be32(e), per = be32(e + 4);
+            const uint32_t nextFirst = r + 1 < runs ? be32(e + 12) : (uint32_t)chunks.size() + 1;
+            if (first < 1 || nextFirst < first) return "bad stsc box";
+            for (uint32_t c = first; c < nextFirst && c <= chunks.size() && sample < count; c++) {
+                uint64_t pos = chunks[c - 1];
+                for (uint32_t k = 0; k < per && sample < count; k++, sample++) {
+                    if (pos + sizes[sample] > f.size()) return "a packet lies outside the file";
+                    out.packetPos.push_back(pos);
+                    out.packetBytes.push_back(sizes[sample]);
+                    pos += sizes[sample];
+                }
+            }
+        }
+        if (sample != count) return "the chunk tables do not cover every sample";
+        out.dataPos = out.packetPos.empty() ? 0 : out.packetPos[0];
+        info.dataPos = out.dataPos;
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < count; i++) total += sizes[i];
+        info.dataSize = total;
+        return "";
+    }
+}
+
+bool has_m4a_extension(const std::string &path)
+{
+    const size_t n = path.size();
+    if (n < 4) return false;
+    std::string e = path.substr(n - 4);
+    for (size_t i = 0; i < e.size(); i++) e[i] = (char)tolower((unsigned char)e[i]);
+    return e == ".m4a" || e == ".mp4";
 }
 
 Bytes build_pcm_caf(double sampleRate, uint32_t channels, uint32_t bits, const uint8_t *pcm, uint64_t pcmBytes)

@@ -18,7 +18,7 @@ namespace alacfile {
 
 typedef std::vector<uint8_t> Bytes;
 
-enum FileKind { kUnknownFile = 0, kWaveFile, kCafFile };
+enum FileKind { kUnknownFile = 0, kWaveFile, kCafFile, kM4aFile };
 
 /* what the sniffers learn about an input file (main.cu:196-385, CAFFileALAC.cpp:395-456) */
 struct InputInfo {
@@ -59,6 +59,7 @@ struct AlacCafContents {
     Bytes cookie;
     std::vector<uint32_t> packetBytes;   /* packets the reference's read loop would decode (main.cu:719-737) */
     uint64_t dataPos;
+    std::vector<uint64_t> packetPos;     /* M4A only: file offset of every packet (chunks need not be contiguous); empty for CAF */
 };
 std::string parse_alac_caf(const Bytes &file, const InputInfo &info, AlacCafContents &out);
 
@@ -79,6 +80,23 @@ Bytes build_alac_sample_description(const Bytes &cookie, uint32_t channels, uint
 /* inverse: cookie + the entry's fields; returns "" or a diagnostic */
 std::string parse_alac_sample_description(const Bytes &stsd, Bytes &cookie, uint32_t &channels, uint32_t &bitsPerChannel,
                                           uint32_t &sampleRate16_16);
+
+/* ---- ALAC in MP4 / M4A (no reference counterpart beyond the sample description of ALACMagicCookieDescription.txt:
+ * 177-216; box layout per ISO/IEC 14496-12) ----
+ * build: 'ftyp' (M4A ), 'moov' { 'mvhd', 'trak' { 'tkhd', 'mdia' { 'mdhd', 'hdlr' soun, 'minf' { 'smhd', 'dinf' { 'dref' url },
+ * 'stbl' { 'stsd' = build_alac_sample_description, 'stts', 'stsc', 'stsz', 'stco' | 'co64' } } } } }, 'mdat': one track, one
+ * chunk holding every packet back to back; timescale = sample rate, one sample = one packet of framesPerPacket frames (the last
+ * one shorter: totalFrames decides).  parse: any chunk layout (stsc runs, stco or co64, fixed or per-sample stsz). */
+struct AlacM4aParams {
+    uint32_t sampleRate, channels, bitDepth, framesPerPacket;
+    uint64_t totalFrames;       /* valid sample-frames of the stream (the duration) */
+};
+Bytes build_alac_m4a(const AlacM4aParams &p, const Bytes &cookie, const std::vector<uint32_t> &packetBytes,
+                     const uint8_t *stream, uint64_t streamBytes);
+/* fills info (isAlac, channels, rate, alacSourceFlag from the sample size, framesPerPacket from stts) and out (cookie,
+ * packetBytes, packetPos); returns "" or a diagnostic */
+std::string parse_alac_m4a(const Bytes &file, InputInfo &info, AlacCafContents &out);
+bool has_m4a_extension(const std::string &path);
 
 /* byte order of CAF big-endian lpcm -> packed little-endian (main.cu:482-507) */
 void swap_samples_in_place(uint8_t *pcm, uint64_t bytes, uint32_t bitsPerChannel);

@@ -109,6 +109,51 @@ int64_t alacfile_parse_alac_caf(const uint8_t *file, uint64_t size, uint8_t *coo
     return (int64_t)c.packetBytes.size();
 }
 
+/* MP4 / M4A: the file image of one ALAC track */
+uint64_t alacfile_build_alac_m4a(uint32_t sample_rate, uint32_t channels, uint32_t bit_depth, uint32_t frames_per_packet,
+                                 uint64_t total_frames, const uint8_t *cookie, uint32_t cookie_size, const uint32_t *packet_bytes,
+                                 uint32_t num_packets, const uint8_t *stream, uint64_t stream_bytes, uint8_t *out, uint64_t cap)
+{
+    AlacM4aParams p = {sample_rate, channels, bit_depth, frames_per_packet, total_frames};
+    Bytes ck(cookie, cookie + cookie_size);
+    std::vector<uint32_t> sizes(packet_bytes, packet_bytes + num_packets);
+    return give(build_alac_m4a(p, ck, sizes, stream, stream_bytes), out, cap);
+}
+
+/* cookie to cookie_out (cap 64), packet sizes / file offsets to sizes_out / pos_out (cap max_packets); returns the packet count,
+ * or -1 with the diagnostic in err */
+int64_t alacfile_parse_alac_m4a(const uint8_t *file, uint64_t size, alacfile_info *info_out, uint8_t *cookie_out,
+                                uint32_t *cookie_size, uint32_t *sizes_out, uint64_t *pos_out, uint32_t max_packets, char *err,
+                                uint32_t errcap)
+{
+    Bytes f(file, file + size);
+    InputInfo info;
+    AlacCafContents c;
+    const std::string e = parse_alac_m4a(f, info, c);
+    if (err && errcap) {
+        strncpy(err, e.c_str(), errcap - 1);
+        err[errcap - 1] = 0;
+    }
+    if (!e.empty()) return -1;
+    info_out->kind = info.kind;
+    info_out->is_alac = info.isAlac;
+    info_out->big_endian_pcm = 0;
+    info_out->sample_rate = info.sampleRate;
+    info_out->channels = info.channels;
+    info_out->bits_per_channel = info.bitsPerChannel;
+    info_out->alac_source_flag = info.alacSourceFlag;
+    info_out->frames_per_packet = info.framesPerPacket;
+    info_out->data_pos = info.dataPos;
+    info_out->data_size = info.dataSize;
+    *cookie_size = (uint32_t)c.cookie.size();
+    if (c.cookie.size() <= 64) memcpy(cookie_out, c.cookie.data(), c.cookie.size());
+    for (size_t i = 0; i < c.packetBytes.size() && i < max_packets; i++) {
+        sizes_out[i] = c.packetBytes[i];
+        pos_out[i] = c.packetPos[i];
+    }
+    return (int64_t)c.packetBytes.size();
+}
+
 void alacfile_swap_samples(uint8_t *pcm, uint64_t bytes, uint32_t bits) { swap_samples_in_place(pcm, bytes, bits); }
 
 uint32_t alacfile_append_ber(uint32_t value, uint8_t *out5)

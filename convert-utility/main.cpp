@@ -9,11 +9,16 @@
  * and container.cpp are plain host C++.
  *
  * Extensions (not in the reference):
+ *   <output>.m4a / .mp4 on encode, an MP4 / M4A input on decode: ALAC in an ISO base media file (one 'alac' track, the
+ *                                             sample description of ALACMagicCookieDescription.txt:177-216) instead of CAF
  *   --batch <in1> <out1> [<in2> <out2> ...]   convert many files in one GPU batch; every output is identical to a
  *                                             single-file run (each file is one independent chain of packets)
  *   --segment-packets K                       encode only: restart the predictor state every K packets so that
  *                                             one long file spreads over the GPU (valid ALAC, NOT byte-identical
  *                                             to the reference's output, about 1 % larger at K = 1)
+ *   --devices N                               with --batch: the files are dealt round-robin to N GPUs, one context and
+ *                                             one host thread per device (replicas: independent files need no exchange
+ *                                             between the GPUs, so there is no RCCL here); outputs are unchanged
  *
  * A single chained file is serial by construction: one file runs as one chain of dependent
  * packets; the GPU pays off with --batch or --segment-packets.
@@ -23,7 +28,10 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include "alac_hip.h"
 
 #include "ALACAudioTypes.h"
 #include "ALACDecoder.h"
@@ -54,6 +62,7 @@ void usage()
     printf("Extensions:\n");
     printf("        alacconvert --batch <in1> <out1> [<in2> <out2> ...]\n");
     printf("        alacconvert --segment-packets K <input wav or caf file> <output caf file>\n");
+    printf("        alacconvert --batch --devices N <in1> <out1> [<in2> <out2> ...]\n");
     printf("\n");
 }
 
@@ -73,7 +82,7 @@ AudioFormatDescription alac_format(const InputInfo &in)
 }
 
 // ---- encode: all jobs share bit depth and channel count; each file is one segment ----
-bool encode_group(std::vector<Job *> &jobs, uint32_t segmentPackets)
+bool encode_group(std::vector<Job *> &jobs, uint32_t segmentPackets, int device)
 {
     const InputInfo &first = jobs[0]->info;
     const uint32_t bps = first.bitsPerChannel >> 3, ch = first.channels;
@@ -82,6 +91,7 @@ bool encode_group(std::vector<Job *> &jobs, uint32_t segmentPackets)
 
     ALACEncoder enc;
     enc.SetFrameSize(frame);
+    if (device >= 0) enc.SetDevice(device);
     AudioFormatDescription outFmt = alac_format(first);
     if (enc.InitializeEncoder(outFmt, 0) != ALAC_noErr) {
         fprintf(stderr, " Cannot initialise the encoder (status %d)\n", enc.LastStatus());
@@ -135,6 +145,7 @@ bool encode_group(std::vector<Job *> &jobs, uint32_t segmentPackets)
         Job &J = *jobs[j];
         ALACEncoder cookieMaker;  // the cookie carries the file's own sample rate
         cookieMaker.SetFrameSize(frame);
+        if (device >= 0) cookieMaker.SetDevice(device);
         AudioFormatDescription f = alac_format(J.info);
         cookieMaker.InitializeEncoder(f, 0);
         uint32_t cookieSize = cookieMaker.GetMagicCookieSize(J.info.channels);
@@ -144,16 +155,23 @@ bool encode_group(std::vector<Job *> &jobs, uint32_t segmentPackets)
         const uint32_t p0 = firstPacket[j], p1 = j + 1 < jobs.size() ? firstPacket[j + 1] : np;
         alacfile::AlacCafParams cp = {J.info.sampleRate, J.info.channels, J.info.bitsPerChannel, frame, J.info.dataSize};
         std::vector<uint32_t> mine(sizes.begin() + p0, sizes.begin() + p1);
-        J.result = alacfile::build_alac_caf(cp, cookie, mine, stream.data() + offs[p0], offs[p1] - offs[p0]);
+        if (alacfile::has_m4a_extension(J.out)) {
+            const alacfile::AlacM4aParams mp = {(uint32_t)J.info.sampleRate, J.info.channels, J.info.bitsPerChannel, frame,
+                                                J.info.dataSize / bytesPerFrame};
+            J.result = alacfile::build_alac_m4a(mp, cookie, mine, stream.data() + offs[p0], offs[p1] - offs[p0]);
+        } else {
+            J.result = alacfile::build_alac_caf(cp, cookie, mine, stream.data() + offs[p0], offs[p1] - offs[p0]);
+        }
     }
     return true;
 }
 
 // ---- decode: jobs with identical cookies decode in one batch ----
-bool decode_group(std::vector<Job *> &jobs, const std::vector<alacfile::AlacCafContents> &contents)
+bool decode_group(std::vector<Job *> &jobs, const std::vector<alacfile::AlacCafContents> &contents, int device)
 {
     const Bytes &cookie = contents[0].cookie;
     ALACDecoder dec;
+    if (device >= 0) dec.SetDevice(device);
     Bytes cookieCopy(cookie);
     if (dec.Init(cookieCopy.data(), (uint32_t)cookieCopy.size(), 0) != ALAC_noErr) {
         fprintf(stderr, " Cannot initialise the decoder from the magic cookie\n");
@@ -177,6 +195,7 @@ bool decode_group(std::vector<Job *> &jobs, const std::vector<alacfile::AlacCafC
         uint64_t pos = contents[j].dataPos;
         for (size_t p = 0; p < contents[j].packetBytes.size(); p++) {
             const uint32_t sz = contents[j].packetBytes[p];
+            if (!contents[j].packetPos.empty()) pos = contents[j].packetPos[p];  // M4A: chunks need not be contiguous
             stream.insert(stream.end(), jobs[j]->file.begin() + pos, jobs[j]->file.begin() + pos + sz);
             sizes.push_back(sz);
             pos += sz;
@@ -221,7 +240,7 @@ int main(int argc, char *argv[])
 {
     std::vector<std::string> files;
     bool batch = false, malformed = argc < 2;
-    uint32_t segmentPackets = 0;
+    uint32_t segmentPackets = 0, devices = 0;
     for (int i = 1; i < argc && !malformed; i++) {
         const std::string a = argv[i];
         if (a == "-h") {
@@ -231,6 +250,9 @@ int main(int argc, char *argv[])
         } else if (a == "--segment-packets" && i + 1 < argc) {
             segmentPackets = (uint32_t)strtoul(argv[++i], nullptr, 10);
             if (segmentPackets == 0) malformed = true;
+        } else if (a == "--devices" && i + 1 < argc) {
+            devices = (uint32_t)strtoul(argv[++i], nullptr, 10);
+            if (devices == 0) malformed = true;
         } else if (!a.empty() && a[0] == '-') {
             printf("unknown option: %s\n", a.c_str());  // main.cu:92-96
             malformed = true;
@@ -239,6 +261,7 @@ int main(int argc, char *argv[])
         }
     }
     if (!malformed && (files.size() < 2 || (files.size() & 1) || (!batch && files.size() != 2))) malformed = true;
+    if (!malformed && devices && !batch) malformed = true;  // one file is one serial chain: nothing to deal out
     if (malformed) {
         usage();
         return 1;
@@ -282,7 +305,9 @@ int main(int argc, char *argv[])
         std::string key;
         if (J.info.isAlac) {
             alacfile::AlacCafContents c;
-            const std::string err = alacfile::parse_alac_caf(J.file, J.info, c);
+            InputInfo again;
+            const std::string err = J.info.kind == alacfile::kM4aFile ? alacfile::parse_alac_m4a(J.file, again, c)
+                                                                      : alacfile::parse_alac_caf(J.file, J.info, c);
             if (!err.empty()) {
                 fprintf(stderr, " %s: \"%s\"\n", err.c_str(), J.in.c_str());
                 return 1;
@@ -299,16 +324,68 @@ int main(int argc, char *argv[])
         }
         groups[key].push_back(&J);
     }
+    // one unit of work = the jobs of one group that one device takes
+    struct Work {
+        std::vector<Job *> jobs;
+        std::vector<alacfile::AlacCafContents> contents;
+        bool decode;
+    };
+    uint32_t workers = 1;
+    int firstDevice = -1;  // -1: the classes' default (ALAC_HIP_DEVICE or 0), the single-device behaviour of every round before
+    if (devices) {
+        const int32_t have = alac_hip_device_count();
+        // ALACCONVERT_SHARE_DEVICES=1 (tests on a one-GPU box): the N workers run side by side on the devices there are
+        const bool share = getenv("ALACCONVERT_SHARE_DEVICES") != nullptr;
+        if (have < 1 || ((int32_t)devices > have && !share)) {
+            fprintf(stderr, " --devices %u: only %d GPU(s) visible\n", devices, have);
+            return 1;
+        }
+        workers = devices;
+        firstDevice = 0;
+    }
+    std::vector<std::vector<Work> > perWorker(workers);
+    const int32_t visible = devices ? alac_hip_device_count() : 1;
+    uint32_t next = 0;
     for (std::map<std::string, std::vector<Job *> >::iterator g = groups.begin(); g != groups.end(); ++g) {
         std::vector<Job *> &v = g->second;
-        if (v[0]->info.isAlac) {
-            std::vector<alacfile::AlacCafContents> contents(v.size());
-            for (size_t j = 0; j < v.size(); j++) alacfile::parse_alac_caf(v[j]->file, v[j]->info, contents[j]);
-            if (!decode_group(v, contents)) return 1;
-        } else {
-            if (!encode_group(v, segmentPackets)) return 1;
+        const bool dec = v[0]->info.isAlac;
+        std::vector<Work> parts(workers);
+        for (size_t j = 0; j < v.size(); j++) {
+            Work &w = parts[(next + j) % workers];  // files dealt round-robin, continuing where the last group stopped
+            w.decode = dec;
+            w.jobs.push_back(v[j]);
+            if (dec) {
+                w.contents.push_back(alacfile::AlacCafContents());
+                if (v[j]->info.kind == alacfile::kM4aFile) {
+                    InputInfo again;
+                    alacfile::parse_alac_m4a(v[j]->file, again, w.contents.back());
+                } else {
+                    alacfile::parse_alac_caf(v[j]->file, v[j]->info, w.contents.back());
+                }
+            }
         }
+        for (uint32_t k = 0; k < workers; k++)
+            if (!parts[(next + k) % workers].jobs.empty()) perWorker[(next + k) % workers].push_back(parts[(next + k) % workers]);
+        next = (uint32_t)((next + v.size()) % workers);
     }
+    std::vector<int> ok(workers, 1);
+    auto run = [&](uint32_t k) {
+        const int device = firstDevice < 0 ? -1 : (int)(k % (uint32_t)visible);
+        for (size_t i = 0; i < perWorker[k].size() && ok[k]; i++) {
+            Work &w = perWorker[k][i];
+            ok[k] = w.decode ? decode_group(w.jobs, w.contents, device) : encode_group(w.jobs, segmentPackets, device);
+        }
+    };
+    if (workers == 1) {
+        run(0);
+    } else {
+        // one host thread and one context per device; nothing is shared between them (every Job belongs to one Work)
+        std::vector<std::thread> threads;
+        for (uint32_t k = 0; k < workers; k++) threads.emplace_back(run, k);
+        for (size_t k = 0; k < threads.size(); k++) threads[k].join();
+    }
+    for (uint32_t k = 0; k < workers; k++)
+        if (!ok[k]) return 1;
     for (size_t j = 0; j < jobs.size(); j++) {
         if (!alacfile::write_file(jobs[j].out, jobs[j].result)) {
             fprintf(stderr, " Cannot open file \"%s\"\n", jobs[j].out.c_str());

@@ -20,6 +20,8 @@ public:
 
     /* codec/ALACDecoder.cu:109-190 */
     int32_t Init(void *inMagicCookie, uint32_t inMagicCookieSize, int X = 0);
+    /* Extension: the HIP device of this object's context (before Init; default: environment ALAC_HIP_DEVICE, else 0) */
+    void SetDevice(int device) { mDevice = device; }
 
     /* upstream form: decode the packet at bits->cur into host sampleBuffer (packed LE interleaved) */
     int32_t Decode(BitBuffer *bits, uint8_t *sampleBuffer, uint32_t numSamples, uint32_t numChannels,
@@ -43,6 +45,7 @@ public:
 
 private:
     alac_hip_ctx *mCtx;
+    int mDevice; /* -1: ALAC_HIP_DEVICE or 0 */
     std::vector<uint8_t> mCookie;
     std::vector<uint8_t> mQueued;         /* fork form: queued packet bytes */
     std::vector<uint32_t> mQueuedSizes;

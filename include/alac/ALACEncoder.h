@@ -29,6 +29,10 @@ public:
 
     void SetFastMode(bool fast) { mFastMode = fast; }
     void SetFrameSize(uint32_t frameSize) { mFrameSize = frameSize; } /* before InitializeEncoder */
+    /* Extension: the HIP device this object's context is created on (before InitializeEncoder; default: environment
+     * ALAC_HIP_DEVICE, else 0).  One object = one device = one stream; objects on different devices may be driven from
+     * different threads (alacconvert --batch --devices N). */
+    void SetDevice(int device) { mDevice = device; }
 
     void GetConfig(ALACSpecificConfig &config);
     uint32_t GetMagicCookieSize(uint32_t inNumChannels);
@@ -62,6 +66,7 @@ protected:
 
 private:
     alac_hip_ctx *mCtx;
+    int mDevice; /* -1: ALAC_HIP_DEVICE or 0 */
     int16_t mState[64 * 8]; /* rows 3 and 7 of mCoefsU/V[first channel of every element] (codec/ALACEncoder.h:89-90) */
     bool mStateValid;
     std::vector<uint8_t> mBatchStream;

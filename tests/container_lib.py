@@ -89,6 +89,33 @@ class Container:
         n = self.lib.alacfile_parse_stsd(_u8(box), C.c_uint64(len(box)), ck, f)
         return None if n < 0 else (bytes(ck[:n]), f[0], f[1], f[2])
 
+    def build_alac_m4a(self, rate, ch, bits, total_frames, cookie, sizes, stream, frames_per_packet=4096):
+        sz = np.ascontiguousarray(sizes, np.uint32)
+        cap = len(stream) + 4096 + 4 * len(sz)
+        out = (C.c_uint8 * cap)()
+        self.lib.alacfile_build_alac_m4a.restype = C.c_uint64
+        self.lib.alacfile_build_alac_m4a.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,
+                                                     C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p,
+                                                     C.c_uint64]
+        n = self.lib.alacfile_build_alac_m4a(rate, ch, bits, frames_per_packet, total_frames, _u8(cookie), len(cookie),
+                                             sz.ctypes.data if len(sz) else None, len(sz), _u8(stream), len(stream), out, cap)
+        assert n <= cap
+        return bytes(out[:n])
+
+    def parse_alac_m4a(self, data, max_packets=1 << 16):
+        """-> (info, cookie, sizes, positions) or the diagnostic string"""
+        info, err = Info(), C.create_string_buffer(160)
+        cookie, csize = (C.c_uint8 * 64)(), C.c_uint32(0)
+        sizes, pos = np.zeros(max_packets, np.uint32), np.zeros(max_packets, np.uint64)
+        self.lib.alacfile_parse_alac_m4a.restype = C.c_int64
+        self.lib.alacfile_parse_alac_m4a.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        n = self.lib.alacfile_parse_alac_m4a(_u8(data), len(data), C.byref(info), cookie, C.byref(csize), sizes.ctypes.data,
+                                             pos.ctypes.data, max_packets, err, 160)
+        if n < 0:
+            return err.value.decode()
+        return info, bytes(cookie[:csize.value]), sizes[:n].copy(), pos[:n].copy()
+
     def ber(self, v):
         out = (C.c_uint8 * 5)()
         n = self.lib.alacfile_append_ber(C.c_uint32(v), out)

@@ -25,8 +25,10 @@ def binary(gpu_ctx):
     return BIN
 
 
-def run(binary, *args):
-    p = subprocess.run([binary] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+def run(binary, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([binary] + [str(a) for a in args], capture_output=True, text=True, timeout=300, env=e)
     return p.returncode, p.stdout, p.stderr
 
 
@@ -99,6 +101,81 @@ def test_batch_outputs_equal_single_file_outputs(binary, oracle, tmp_path):
     assert rc == 0, err
     for i, (_, _, pcm) in enumerate(wants):
         assert (tmp_path / f"back{i}.wav").read_bytes()[44:] == pcm
+
+
+def test_batch_dealt_to_several_devices(binary, oracle, tmp_path):
+    """--batch --devices N: the files go round-robin to N workers, one host thread and one context per device (replicas, no
+    exchange).  A one-GPU box has one device: ALACCONVERT_SHARE_DEVICES=1 lets the three worker threads share it, which
+    exercises the dealing and the threads; without it the tool refuses more devices than it sees.  Outputs are those of the
+    single-device batch."""
+    specs = [(16, 2, 4096 * 3 + 100, 41), (16, 1, 5000, 42), (24, 2, 4096 + 9, 43), (16, 2, 4096 * 5, 44), (16, 2, 33, 45),
+             (16, 1, 4096 * 2 + 1, 46), (16, 2, 4096 * 2 + 7, 47)]
+    args, wants = [], []
+    for i, (bits, ch, frames, seed) in enumerate(specs):
+        pcm = music_like(frames, ch, bits, seed)
+        wav = co.make_wav(pcm, ch, 44100, bits)
+        src, dst = tmp_path / f"in{i}.wav", tmp_path / f"out{i}.caf"
+        src.write_bytes(wav)
+        args += [src, dst]
+        wants.append((dst, oracle_encode(oracle, wav, bits, ch, 44100)[0], pcm))
+    rc, _, err = run(binary, "--batch", "--devices", 3, *args, env={"ALACCONVERT_SHARE_DEVICES": "1"})
+    assert rc == 0, err
+    for dst, want, _ in wants:
+        assert dst.read_bytes() == want
+    back = []
+    for i, (dst, _, _) in enumerate(wants):
+        back += [dst, tmp_path / f"back{i}.wav"]
+    rc, _, err = run(binary, "--batch", "--devices", 2, *back, env={"ALACCONVERT_SHARE_DEVICES": "1"})
+    assert rc == 0, err
+    for i, (_, _, pcm) in enumerate(wants):
+        assert (tmp_path / f"back{i}.wav").read_bytes()[44:] == pcm
+    rc, _, err = run(binary, "--batch", "--devices", 1, *args)
+    assert rc == 0, err
+    import torch
+    if torch.cuda.device_count() < 64:
+        rc, _, err = run(binary, "--batch", "--devices", 64, *args)
+        assert rc == 1 and "GPU(s) visible" in err
+    rc, out, _ = run(binary, "--devices", 2, args[0], args[1])  # one file is one serial chain: nothing to deal out
+    assert rc == 1 and out.startswith("Usage:")
+
+
+@pytest.mark.parametrize("bits,ch,frames", [(16, 2, 4096 * 3 + 50), (24, 2, 4096 + 7), (16, 1, 9000), (16, 6, 4096 + 100)])
+def test_m4a_out_and_in(binary, oracle, tmp_path, bits, ch, frames):
+    """<out>.m4a on encode, an M4A input on decode.  The packets and the cookie inside the M4A are those of the CAF
+    the same input gives (the reference-identical file), the box tables describe them (tests/test_m4a.py walks them
+    independently), and the file decodes back to the input — alone and in a batch next to a CAF."""
+    import struct
+    from container_lib import Container
+    pcm = music_like(frames, ch, bits, 60 + ch)
+    wav = co.make_wav(pcm, ch, 44100, bits)
+    src, m4a, caf = tmp_path / "in.wav", tmp_path / "out.m4a", tmp_path / "out.caf"
+    src.write_bytes(wav)
+    assert run(binary, src, m4a)[0] == 0 and run(binary, src, caf)[0] == 0
+    ct = Container()
+    info, cookie, sizes, pos = ct.parse_alac_m4a(m4a.read_bytes())
+    ck2, sizes2, dpos = ct.parse_alac_caf(caf.read_bytes())
+    assert cookie == ck2 and list(sizes) == list(sizes2)
+    f, c = m4a.read_bytes(), caf.read_bytes()
+    assert f[int(pos[0]):int(pos[0]) + int(sizes.sum())] == c[dpos:dpos + int(sizes2.sum())]
+    i = f.index(b"mdhd")
+    assert struct.unpack(">II", f[i + 16:i + 24]) == (44100, frames)
+    if ch <= 2:
+        back = tmp_path / "back.wav"
+        rc, _, err = run(binary, m4a, back)
+        assert rc == 0, err
+        assert back.read_bytes()[44:] == pcm
+        b1, b2 = tmp_path / "b1.wav", tmp_path / "b2.wav"
+        rc, _, err = run(binary, "--batch", m4a, b1, caf, b2)
+        assert rc == 0, err
+        assert b1.read_bytes() == b2.read_bytes() == back.read_bytes()
+    else:
+        back = tmp_path / "back.caf"
+        rc, _, err = run(binary, m4a, back)
+        assert rc == 0, err
+        assert back.read_bytes().endswith(pcm)
+    again = tmp_path / "again.mp4"  # PCM CAF / WAV in, .mp4 out: the same container
+    assert run(binary, back, again)[0] == 0
+    assert again.read_bytes() == f
 
 
 def test_segment_mode_is_valid_alac_and_decodes_to_the_input(binary, oracle, tmp_path):
