@@ -92,14 +92,18 @@ def test_packet_counts_around_the_entropy_wave_size(gpu_ctx, channels, n):
     assert torch.equal(out, d_pcm)
 
 
-def test_large_ragged_batch_in_the_separate_launch_regime(gpu_ctx, oracle):
+@pytest.mark.parametrize("depth", [16, 24, 20, 32])
+def test_large_ragged_batch_in_the_separate_launch_regime(gpu_ctx, oracle, depth):
     """40 000 stereo packets (80 000 chains: the separate-launch decode regime with its work lists) whose lengths are
-    drawn per packet — full frames, lengths that are not multiples of four, and lengths below 16 samples, which the
+    drawn per packet — full frames, lengths that are not multiples of four or eight, and lengths below 16 samples, which the
     one-lane predictor does not take (generic predictor + k_dec_unmix's leftover list) — mixed with the generator's
-    silent, noisy (uncompressed) and tonal classes: every packet's valid frames must come back, oracle bytes on a sample"""
+    silent, noisy (uncompressed) and tonal classes: every packet's valid frames must come back, oracle bytes on a sample.
+    16, 20 and 24 bits take the pair form (the predictor lanes of a packet un-mix, re-attach the shifted-off bytes and
+    write the PCM themselves); 32 bits (two shifted-off bytes) the one-lane predictor + k_dec_unmix."""
     import torch
     frame, n = 256, 40000
-    fmt = alac_amd.make_format(frame, 16, 2)
+    fmt = alac_amd.make_format(frame, depth, 2)
+    bpf = fmt.bytes_per_frame
     rng = np.random.default_rng(77)
     ns = np.full(n, frame, np.int32)
     pick = rng.random(n)
@@ -112,19 +116,24 @@ def test_large_ragged_batch_in_the_separate_launch_regime(gpu_ctx, oracle):
     offs = b["offsets"].cpu().numpy()
     stream = b["out"][:int(offs[-1])].cpu().numpy()
     pcm = d_pcm.cpu().numpy()
-    enc = oracle.encoder(frame, 16, 2)
+    enc = oracle.encoder(frame, depth, 2)
     for p in list(range(0, n, 997)) + [n - 1] + [int(i) for i in np.nonzero(ns < 16)[0][:8]]:
         enc.reset()
-        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * 4], int(ns[p]))
+        pk = enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + ns[p] * bpf], int(ns[p]))
         assert np.array_equal(stream[offs[p]:offs[p + 1]], pk), p
-    out, dns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), b["out"], b["offsets"], n)
+    sentinel = torch.full((n * fmt.packet_bytes,), 0xA7, dtype=torch.uint8, device="cuda")
+    out_bufs = (sentinel, torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"))
+    out, dns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), b["out"], b["offsets"], n, out=out_bufs)
     gpu_ctx.synchronize()
     assert int(st.abs().sum()) == 0 and torch.equal(dns.to(torch.int32), d_ns)
-    got = out.view(torch.int32).reshape(n, frame)
-    want = d_pcm.view(torch.int32).reshape(n, frame)
-    valid = torch.arange(frame, device="cuda")[None, :] < d_ns[:, None]
-    bad = ((got != want) & valid).any(dim=1)
+    got = out.reshape(n, frame, bpf)
+    want = d_pcm.reshape(n, frame, bpf)
+    valid = (torch.arange(frame, device="cuda")[None, :] < d_ns[:, None])[:, :, None]
+    bad = ((got != want) & valid).any(dim=2).any(dim=1)
     assert not bool(bad.any()), ("packets differ", torch.nonzero(bad)[:8].flatten().tolist(), ns[torch.nonzero(bad)[:8].flatten().cpu().numpy()])
+    # nothing is written behind a short packet's frames
+    spill = ((got != 0xA7) & ~valid).any(dim=2).any(dim=1)
+    assert not bool(spill.any()), ("bytes written past the packet's frames", torch.nonzero(spill)[:8].flatten().tolist())
 
 
 def _bits(value, width):

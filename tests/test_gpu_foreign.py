@@ -96,11 +96,14 @@ def test_foreign_packets_mixed_with_own(gpu_ctx, oracle, depth, channels, frame,
     assert not bad, bad[:10]
 
 
-def test_foreign_packets_in_the_separate_launch_regime(gpu_ctx, oracle):
-    """35 000 stereo packets (70 000 chains: work lists, one-lane predictor, pairs) of which every 50th is foreign"""
+@pytest.mark.parametrize("depth", [16, 24, 20])
+def test_foreign_packets_in_the_separate_launch_regime(gpu_ctx, oracle, depth):
+    """35 000 stereo packets (70 000 chains: work lists, one-lane predictor, pairs — 16-bit words and 20- / 24-bit six-byte
+    frames with their shifted-off bytes) of which every 50th is foreign"""
     import torch
     frame, n = 128, 35000
-    fmt = alac_amd.make_format(frame, 16, 2)
+    fmt = alac_amd.make_format(frame, depth, 2)
+    bpf = fmt.bytes_per_frame
     d_pcm = gpu_ctx.synth_pcm(0, n, fmt)
     b = gpu_ctx.encode(fmt, d_pcm, n)
     gpu_ctx.synchronize()
@@ -108,20 +111,20 @@ def test_foreign_packets_in_the_separate_launch_regime(gpu_ctx, oracle):
     stream = b["out"][:int(offs[-1])].cpu().numpy()
     pcm = d_pcm.cpu().numpy()
     pk = [stream[offs[p]:offs[p + 1]] for p in range(n)]
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + depth)
     f = forge.Forger(oracle)
-    fpk, fpcm, fok = forge.forge_batch(f, rng, n // 50, 16, 2, frame)
+    fpk, fpcm, fok = forge.forge_batch(f, rng, n // 50, depth, 2, frame)
     where = list(range(7, n, 50))[:len(fpk)]
     for w, a in zip(where, fpk):
         pk[w] = a
-    ck = forge.cookie(frame, 16, 2)
+    ck = forge.cookie(frame, depth, 2)
     out, ns, st, _ = gpu_decode(gpu_ctx, ck, pk)
     assert int(np.abs(st).sum()) == 0
     dec = oracle.decoder(ck)
     for w, a in zip(where, fpk):
-        ost, want, m = dec.decode_packet(a, 4)
+        ost, want, m = dec.decode_packet(a, bpf)
         assert ost == 0 and ns[w] == m
-        assert np.array_equal(out[w * fmt.packet_bytes:w * fmt.packet_bytes + m * 4], want), w
+        assert np.array_equal(out[w * fmt.packet_bytes:w * fmt.packet_bytes + m * bpf], want), (w, fok.info[where.index(w)])
     keep = np.ones(n, bool)
     keep[where] = False
     got = out.reshape(n, fmt.packet_bytes)[keep]
