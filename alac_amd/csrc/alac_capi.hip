@@ -61,6 +61,7 @@ AlacOptions alac_options_from_env()
     if (const char *e = getenv("ALAC_HIP_DECODER")) o.laneDecoder = strcmp(e, "lane") == 0;
     if (const char *e = getenv("ALAC_HIP_DEC_FUSED")) o.decFused = *e ? (e[0] == '0' ? 0 : 1) : -1;
     o.decPair = env_int("ALAC_HIP_DEC_PAIR", o.decPair) != 0;
+    o.decDirect = env_int("ALAC_HIP_DEC_DIRECT", o.decDirect) != 0;
     o.stageTaps = env_int("ALAC_HIP_STAGE_TAPS", o.stageTaps) != 0;
     o.loseHandoff = env_int("ALAC_HIP_DEBUG_LOSE_HANDOFF", o.loseHandoff) == 1;
     return o;
@@ -75,7 +76,8 @@ const AlacOptionKey *alac_option_keys(uint32_t *count)
         {"fused", &AlacOptions::fused, 0, 1},          {"fold", &AlacOptions::fold, 0, 1},
         {"fast_mode", &AlacOptions::fastMode, 0, 1},   {"encoder_lane", &AlacOptions::laneEncoder, 0, 1},
         {"decoder_lane", &AlacOptions::laneDecoder, 0, 1}, {"dec_fused", &AlacOptions::decFused, -1, 1},
-        {"dec_pair", &AlacOptions::decPair, 0, 1},     {"stage_taps", &AlacOptions::stageTaps, 0, 1},
+        {"dec_pair", &AlacOptions::decPair, 0, 1},     {"dec_direct", &AlacOptions::decDirect, 0, 1},
+        {"stage_taps", &AlacOptions::stageTaps, 0, 1},
         {"debug_lose_handoff", &AlacOptions::loseHandoff, 0, 1}, {"debug_waves", &AlacOptions::debugWaves, 0, 1},
     };
     if (count) *count = (uint32_t)(sizeof(table) / sizeof(table[0]));
@@ -955,6 +957,7 @@ int32_t alac_hip_decode(alac_hip_ctx *ctx, const uint8_t *h_cookie, uint32_t coo
     da.ho = handoff_ctl(ctx);
     da.optFused = ctx->opt.decFused;
     da.optPair = ctx->opt.decPair;
+    da.optDirect = ctx->opt.decDirect;
     hipError_t e;
     if (use_lane_decoder(ctx)) {
         e = launch_decode(da, ctx->stream);

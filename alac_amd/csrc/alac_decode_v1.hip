@@ -113,7 +113,15 @@ __device__ __forceinline__ uint32_t wave_min_dec(uint32_t v)
 
 struct DecV1Args {
     DecodeArgs d;
-    const uint32_t *words;   // staged stream
+    const uint32_t *words;   // staged stream (MSB-first words + 64 zero words, k_dec_stage) — or, DIRECT (raw != null), unused
+    // DIRECT (round 4, the separate launches of a large batch): the kernels read the CALLER's stream as little-endian dwords
+    // and swap them as they load (one v_perm_b32 per word) instead of reading a staged copy — k_dec_stage's pass over the whole
+    // stream (1.7 GB of traffic, 0.35 ms at 125 000 packets) is gone.  Word i comes from raw[i] while i < tailStart, from the
+    // small copy tail[i - tailStart] behind that (k_dec_tail: the stream's last 16 whole dwords, its ragged end and zeros), so
+    // that no load ever touches a byte behind the caller's buffer; tailStart = max(0, (total bytes >> 2) - 16) is computed on
+    // the device (the total lives there).
+    const uint32_t *raw;     // null: staged
+    const uint32_t *tail;    // kDecTailWords words
     uint64_t capWords;
     int32_t *plane;          // [packet][channel][frameSize]
     uint32_t *prog;          // fused launch: [packet][2] residuals completed per channel (0xffffffff = all)
@@ -128,6 +136,43 @@ struct DecV1Args {
     uint32_t lists;          // separate launches: k_dec_header sorts the packets / chains into work lists (dec_lists below)
     uint32_t pairs;          // ... and lists the packets whose two chains unpc_pair_body takes (option dec_pair, one-lane predictor)
 };
+
+constexpr uint32_t kDecTailWords = 128;  // 16 whole dwords + a ragged one + the 64 zero words the readers may run into, rounded up
+__device__ __forceinline__ uint64_t dec_tail_start(const DecV1Args &V)
+{
+    const uint64_t fw = V.d.offsets[V.d.numPackets] >> 2;
+    return fw > 16 ? fw - 16 : 0;
+}
+// word i of the stream, MSB first
+__device__ __forceinline__ uint32_t dec_word(const DecV1Args &V, uint64_t tailStart, uint64_t i)
+{
+    if (!V.raw) return V.words[i];
+    const uint64_t t = min(i - tailStart, (uint64_t)(kDecTailWords - 1));
+    return __builtin_bswap32(i < tailStart ? V.raw[i] : V.tail[t]);
+}
+// 16 consecutive words from index w on (w + 16 <= the word limit): DIRECT windows that start in front of tailStart end in front
+// of tailStart + 16 = the stream's last whole dword
+__device__ __forceinline__ const uint32_t *dec_window(const DecV1Args &V, uint64_t tailStart, uint64_t w)
+{
+    if (!V.raw) return V.words + w;
+    return w < tailStart ? V.raw + w : V.tail + min(w - tailStart, (uint64_t)(kDecTailWords - 16));
+}
+
+// k_dec_tail (DIRECT): the end of the stream as dwords in the caller's byte order, zero-filled behind the last byte
+__global__ __launch_bounds__(kDecTailWords) void k_dec_tail(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets, uint32_t *tail)
+{
+    const uint64_t total = offsets[numPackets];
+    const uint64_t fw = total >> 2, ts = fw > 16 ? fw - 16 : 0;
+    const uint64_t i = ts + threadIdx.x;
+    uint32_t v = 0;
+    if ((i + 1) * 4 <= total) {
+        v = ((const uint32_t *)stream)[i];
+    } else {
+        for (uint32_t b = 0; b < 4; b++)
+            if (i * 4 + b < total) v |= (uint32_t)stream[i * 4 + b] << (8 * b);
+    }
+    tail[threadIdx.x] = v;
+}
 
 // Work lists of the separate-launch regime, built by k_dec_header (one lane per packet) in the progress words, which that
 // regime does not use:  [0, 2n) chains the one-lane predictor takes, 4-tap chains from the front, 8-tap chains from the back
@@ -287,7 +332,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         // (2) an uncompressed element's fixed-width payload must end inside the packet (the reference's overrun test,
         // codec/ALACDecoder.cu:996-1000, returns kALAC_ParamError for the same packet).
         const uint64_t stagedBytes = (V.capWords - 64) * 4;  // k_dec_stage keeps 64 zero words behind what it copies
-        if (off + nbytes > stagedBytes) status = -50;
+        if (!V.raw && off + nbytes > stagedBytes) status = -50;  // (DIRECT reads the caller's stream: nothing is truncated)
         if (haveElement && R.escape && hpos + (uint64_t)R.numSamples * R.elementChannels * A.bitDepth > nbytes * 8) status = -50;
     }
     if (live) {
@@ -358,7 +403,7 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
     const uint32_t ech = rec->elementChannels, n = rec->numSamples, w = A.bitDepth;
     const uint64_t off = A.offsets[p];
     const uint64_t bitBase = (off & 3) * 8 + rec->pad;
-    const uint32_t *words = V.words + (off >> 2);
+    const uint64_t wbase = off >> 2, tailStart = dec_tail_start(V);
     const uint64_t lastWord = V.capWords - 2 - (off >> 2);  // k_dec_header has checked the payload; never index past the stage
     int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
     // pad2 (k_dec_header): a 16-bit stereo element into a stereo frame — the fields ARE the PCM (codec/ALACDecoder.cu:856-874),
@@ -379,8 +424,8 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
                 const uint64_t b = bitBase + ((uint64_t)(j < n ? j : 0) * ech + (c < ech ? c : 0)) * w;
                 const uint32_t i = (uint32_t)min((uint64_t)(b >> 5), lastWord);
                 shs[u][c] = (uint32_t)(b & 31);
-                hi[u][c] = words[i];
-                lo[u][c] = words[i + 1];
+                hi[u][c] = dec_word(V, tailStart, wbase + i);
+                lo[u][c] = dec_word(V, tailStart, wbase + i + 1);
             }
         }
 #pragma unroll
@@ -445,20 +490,22 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
     const DecodeArgs &A = V.d;
     const uint32_t wb = (1u << A.kb) - 1;
     const uint64_t wordLimit = min(V.capWords, ((A.offsets[A.numPackets] + 3) >> 2) + 64);  // what k_dec_stage wrote
+    const uint64_t tailStart = dec_tail_start(V);
+    const bool swap = V.raw != nullptr;  // DIRECT: the caller's byte order
     auto fetch16 = [&](uint32_t rel, uint32_t (&q)[16]) {
         uint64_t w = wordBase + rel;
         const uint64_t lastStart = wordLimit - kWinWords;  // corrupt input may run past the packet: stay inside
         w = w < lastStart ? w : lastStart;
         // four 16-byte loads (the staged words are dword aligned only): a quarter of the L2 requests of sixteen dword loads
         typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
-        const U4 *sw = (const U4 *)(V.words + w);
+        const U4 *sw = (const U4 *)dec_window(V, tailStart, w);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const U4 t = sw[i];
-            q[4 * i] = t.x;
-            q[4 * i + 1] = t.y;
-            q[4 * i + 2] = t.z;
-            q[4 * i + 3] = t.w;
+            q[4 * i] = swap ? __builtin_bswap32(t.x) : t.x;
+            q[4 * i + 1] = swap ? __builtin_bswap32(t.y) : t.y;
+            q[4 * i + 2] = swap ? __builtin_bswap32(t.z) : t.z;
+            q[4 * i + 3] = swap ? __builtin_bswap32(t.w) : t.w;
         }
     };
     auto write16 = [&](uint32_t rel, const uint32_t (&q)[16]) {
@@ -737,9 +784,9 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
         uint64_t w = wordBase + cur0;
         const uint64_t lastStart = wordLimit - kWinWords;
         w = w < lastStart ? w : lastStart;
-        const uint32_t *sw = V.words + w;
+        const uint32_t *sw = dec_window(V, dec_tail_start(V), w);
 #pragma unroll
-        for (int i = 0; i < 16; i++) ringRow[i] = sw[i];
+        for (int i = 0; i < 16; i++) ringRow[i] = V.raw ? __builtin_bswap32(sw[i]) : sw[i];
     }
     asm volatile("" ::: "memory");
     // from here on word indices are relative to the first word staged (cur0): ring slot = index & 31 with no subtraction in
@@ -1173,6 +1220,7 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t bloc
     const bool shifted = DEPTH == 24 && active && rec->bytesShifted != 0;
     const uint64_t pktOff = active ? A.offsets[p] : 0;
     const uint64_t sWordBase = pktOff >> 2, sBit0 = (pktOff & 3) * 8 + (active ? rec->shiftPos : 0);
+    const uint64_t sTail = dec_tail_start(V);
 
     // K outputs of each lane of a pair -> K frames: the U lane takes the first K / 2 frames, the V lane the rest; one DPP
     // exchange per frame hands each lane the sample of the other channel it needs (gpu_unmix16, codec/ALACDecoder.cu:193-223)
@@ -1189,7 +1237,7 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t bloc
                 const uint64_t i0 = min(sWordBase + (b >> 5), V.capWords - (uint64_t)(K / 4 + 2));  // status-0 packets lie inside the stage
                 ssh = (uint32_t)(b & 31);
 #pragma unroll
-                for (int q = 0; q <= K / 4; q++) sw[q] = V.words[i0 + q];
+                for (int q = 0; q <= K / 4; q++) sw[q] = dec_word(V, sTail, i0 + q);
             }
             uint32_t fld[K];  // L0 R0 L1 R1 ... as 24-bit little-endian fields
 #pragma unroll
@@ -1510,7 +1558,8 @@ __device__ __forceinline__ void unmix_part(const DecV1Args &V, uint32_t p, uint3
                     const uint64_t b = bit0 + (uint64_t)j * 16;
                     const uint64_t i = min(wordBase + (b >> 5), V.capWords - 3);  // packets of status 0 lie inside the stage
                     const uint32_t sh = (uint32_t)(b & 31);
-                    const uint32_t w0 = V.words[i], w1 = V.words[i + 1], w2 = V.words[i + 2];
+                    const uint64_t ts = dec_tail_start(V);
+                    const uint32_t w0 = dec_word(V, ts, i), w1 = dec_word(V, ts, i + 1), w2 = dec_word(V, ts, i + 2);
                     x[0] = sh ? (w0 << sh) | (w1 >> (32 - sh)) : w0;
                     x[1] = sh ? (w1 << sh) | (w2 >> (32 - sh)) : w1;
                 }
@@ -1647,7 +1696,19 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     V.lists = fused0 ? 0u : 1u;
     V.pairs = (!fused0 && V.d.optPair != 0) ? 1u : 0u;
     if (V.lists) (void)hipMemsetAsync(dec_lists(V).cnt, 0, kDecCounters * 4, st);
-    if (stageFirst)
+    // DIRECT: separate launches of a mono / stereo stream whose buffer is dword aligned (the fused launch keeps the staged copy:
+    // there the entropy wave is the launch's serial chain and the 38 us copy is cheaper than a swap per word on that chain)
+    // Measured at 125 000 packets (round 4, same box, A/B in one process): 16-bit 5.55 -> 5.39 ms; 24-bit 6.92 -> 7.06 ms — there
+    // half of the stream is shifted-off bytes, which the predictor pairs fetch word by word (a swap and a select per word on
+    // THEIR chain), so 20- / 24- / 32-bit streams keep the staged copy.
+    const bool direct = stageFirst && !fused0 && V.elemBit == nullptr && ((uintptr_t)da.stream & 3) == 0 && V.d.optDirect != 0 &&
+                        da.bitDepth == 16;
+    if (direct) {
+        V.raw = (const uint32_t *)da.stream;
+        V.tail = V.words;                // the first words of the (otherwise unused) staging area
+        V.capWords = 1ull << 40;         // no staging area, no truncation: the word limit is the stream's own end + 64
+        hipLaunchKernelGGL(k_dec_tail, dim3(1), dim3(kDecTailWords), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words));
+    } else if (stageFirst)
         hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
                            V.capWords);
     hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
@@ -1696,6 +1757,8 @@ static DecV1Args decode_v1_args(const DecodeArgs &da, uint32_t *words, uint64_t 
     DecV1Args V;
     V.d = da;
     V.words = words;
+    V.raw = nullptr;
+    V.tail = nullptr;
     V.capWords = capWords;
     V.plane = plane;
     V.prog = prog;

@@ -79,7 +79,10 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels (a second, structurally different
  *                          implementation kept for differential testing)
  *   "dec_fused" (-1/0/1)   decode: entropy wave + its predictor waves in one launch; automatic up to 65 536 chains
- *   "dec_pair" (0/1)       decode, separate launches, 16-bit stereo: the two predictor lanes of a packet un-mix and write the PCM
+ *   "dec_pair" (0/1)       decode, separate launches, 16- / 20- / 24-bit stereo: the two predictor lanes of a packet un-mix and
+ *                          write the PCM
+ *   "dec_direct" (0/1)     decode, separate launches, 16-bit: the kernels read the caller's stream (dword aligned) instead of a
+ *                          staged copy
  *   "stage_taps" (0/1)     alac_hip_pc_block: tap-parallel kernel for 5..30 taps
  *   "debug_waves" (0/1)    diagnostics, see alac_hip_debug_waves_offset
  *   "debug_lose_handoff" (0/1)  TEST switch, the one key that invalidates results by design: producers of the in-launch

@@ -1,7 +1,13 @@
 """GPU: the RCCL re-assembly behind the C-ABI (include/alac_hip.h alac_hip_comm_* / alac_hip_reassemble_*; alac_comm.cpp)
 with ONE rank — every RCCL call of the path runs (ncclGetUniqueId, ncclCommInitRank, both ncclAllGather, the table read-back;
 the send/receive group has no peers at world 1), the shard lands at offset 0 and the gathered size table is the rank's own.
-The offset logic at world > 1 is covered on CPU by tests/test_reassemble_gloo.py and tests/test_comm_model.py."""
+World > 1 runs the SAME C++ (alac_comm.cpp) with its RCCL calls resolved in a test double (tests/cpp/mock_rccl.cpp: ranks are
+threads of one process on the one GPU; RCCL itself refuses two ranks on a device): placement at the prefix-sum offsets,
+ragged shards, the group's send/receive matching, the all-ranks-alike refusal.  tests/test_reassemble_gloo.py keeps the
+torch.distributed form of the same exchange under gloo."""
+import os
+import subprocess
+import sys
 import numpy as np
 import pytest
 
@@ -58,3 +64,17 @@ def test_comm_argument_checks():
         Comm(0, bytes(128), 1, 1)  # rank >= world
     with pytest.raises(AlacError):
         Comm(0, bytes(128), 0, 0)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,packets,mode", [(3, "300,300,300", ""), (2, "64,200", ""), (4, "100,7,256,31", "refuse")])
+def test_several_ranks_over_the_mock(gpu_ctx, world, packets, mode):
+    """the product's N > 1 exchange, every RCCL call resolved in tests/cpp/libmock_rccl.so (its own process: the library binds
+    librccl once)"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "libmock_rccl.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ALAC_HIP_RCCL_LIB=os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_mock_worker.py"), str(world), packets, mode],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0 and p.stdout.strip().startswith("OK"), (p.stdout[-1500:], p.stderr[-1500:])

@@ -22,6 +22,7 @@ VARIANTS = {
     "throughput-regime": {"thru": 1},
     "positions-not-overlapped": {"overlap_pos": 0},
     "unfused-decode-chains-not-paired": {"dec_fused": 0, "dec_pair": 0},
+    "unfused-decode-from-a-staged-copy": {"dec_fused": 0, "dec_direct": 0},
     "tiny-batch-coder-not-split": {"split_coder": 0},
 }
 
