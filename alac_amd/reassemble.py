@@ -11,6 +11,10 @@ shards before it.  The exchange is
 Works on any torch.distributed backend ("nccl" = RCCL over xGMI on the GPU node: the group becomes one
 ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd; "gloo" on CPU for the tests).  xGMI is point to point, so every rank
 receives its 7 peers' shards over 7 different links at once.
+
+Since round 4 the PRODUCT's form of this exchange is C++ on librccl behind the C-ABI (alac_hip_comm_* / alac_hip_reassemble_*,
+alac_amd/csrc/alac_comm.cpp; bench.py uses that one).  This module is the same protocol on torch.distributed: it is what the
+CPU suite can run (gloo, world 2 and 3) and it keeps the padded all-gather as a second exchange mode for A/B runs.
 """
 import torch
 import torch.distributed as dist
@@ -57,12 +61,19 @@ class Reassembler:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         self.padded_mode = bool(flag.item())
         self.padded = None
+        self._caps = {}
 
     def begin(self, shard, length, sizes=None):
         """shard: 1-D uint8 tensor whose first `length` bytes are this rank's packets; length: int64 tensor with one
         element on the shard's device; sizes: optional int32 tensor [packets per rank] (the same count on every rank)."""
         dev = shard.device
-        mine = torch.stack([length.reshape(()).to(torch.int64), torch.tensor(shard.numel(), dtype=torch.int64, device=dev)])
+        # the capacity as a device tensor cached per (device, size): torch.tensor(n, device=cuda) is a synchronous pageable
+        # host-to-device copy, and begin() must not wait for the GPU (ADVICE r3)
+        key = (str(dev), shard.numel())
+        cap = self._caps.get(key)
+        if cap is None:
+            cap = self._caps[key] = torch.full((), shard.numel(), dtype=torch.int64, device=dev)
+        mine = torch.stack([length.reshape(()).to(torch.int64), cap])
         table = torch.empty(2 * self.world, dtype=torch.int64, device=dev)
         _all_gather_flat(table, mine, self.group, self.gloo)
         table = table.view(self.world, 2)
@@ -137,6 +148,9 @@ class Reassembler:
 def reassemble_shards(shard, length, group=None, cache=None, sizes=None, mode=None):
     """One-shot form: returns dict(stream=<uint8 tensor, all shards in rank order>, total, lens=<int64[world]>,
     offsets=<int64[world+1]>, sizes).  `cache` (a previous return value) lets the stream buffer be reused."""
+    if cache and mode is not None and (mode == "allgather") != cache["_ra"].padded_mode:
+        raise ValueError("reassemble_shards: `mode` differs from the mode the cached Reassembler was constructed with "
+                         "(the mode is a collective decision taken once, at construction)")
     ra = cache["_ra"] if cache else Reassembler(group, mode)
     out = ra.finish(ra.begin(shard, length, sizes))
     out["_ra"] = ra

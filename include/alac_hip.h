@@ -142,8 +142,11 @@ int32_t alac_hip_encode(alac_hip_ctx *ctx, const alac_hip_format *fmt, const voi
 /* The same with the caller's bound on the packets of a segment.  The pipeline runs once per packet position of the longest
  * segment, so the host has to know that length: alac_hip_encode reads d_seg_first back (one blocking copy per call) when it is
  * given a table; here max_segment_packets (> 0) is taken on trust, nothing is read back and the call stays asynchronous.  The
- * table is checked on the device (ascending, 0 .. num_packets, no segment above the bound); if it fails, the results are
- * invalid and the next alac_hip_synchronize returns kALAC_ParamError.  An over-estimate only costs idle launches.
+ * table is checked on the device (ascending, 0 .. num_packets, no segment above the bound); if it fails, the next
+ * alac_hip_synchronize returns kALAC_ParamError and NOTHING has been written to d_out (offsets are all zero): every kernel
+ * tests the table entry it uses against num_packets and the bound before it forms a packet index (a segment that fails has
+ * no packets), and the size scan and the packer produce nothing once the check has failed — an unvalidated table can make
+ * the call fail, never make it read or write out of bounds.  An over-estimate only costs idle launches.
  * max_segment_packets = 0: exactly alac_hip_encode.  (The fork's InitializeSampling has no counterpart: one file, one chain.) */
 int32_t alac_hip_encode_segmented(alac_hip_ctx *ctx, const alac_hip_format *fmt, const void *d_pcm,
                                   const uint32_t *d_num_samples, uint32_t num_packets,

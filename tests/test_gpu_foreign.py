@@ -145,3 +145,26 @@ def test_unsupported_and_skipped_elements(gpu_ctx, oracle):
     for p in (0, 2, 4):
         ost, want, n = dec.decode_packet(pk[p], 4)
         assert np.array_equal(out[p * fmt.packet_bytes:p * fmt.packet_bytes + n * 4], want)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_foreign_streams(gpu_ctx, oracle, seed):
+    """randomised: depth, channels, frame size (odd ones too), cookie parameters and 40-90 forged packets per case, decoded in
+    one call — GPU == oracle (== source where the forger guarantees losslessness).  tools/fuzz_soak.py runs more seeds."""
+    rng = np.random.default_rng(7000 + seed)
+    depth = int(rng.choice([16, 16, 24, 20, 32]))
+    channels = int(rng.choice([1, 2, 2]))
+    frame = int(rng.choice([4096, 1024, 512, 100, 333, 64, 17, 2048, 8, 24]))
+    pb, mb, kb = int(rng.choice([40, 40, 20, 63, 255, 1])), int(rng.choice([10, 10, 1, 30, 255])), int(rng.choice([14, 14, 1, 8, 16]))
+    count = int(rng.integers(40, 91))
+    pk, pcm, ok = forge.forge_batch(forge.Forger(oracle), rng, count, depth, channels, frame, pb, mb, kb)
+    ck = forge.cookie(frame, depth, channels, pb, mb, kb)
+    out, ns, st, fmt = gpu_decode(gpu_ctx, ck, pk)
+    dec = oracle.decoder(ck)
+    bpf = fmt.bytes_per_frame
+    for p, (a, src, k) in enumerate(zip(pk, pcm, ok)):
+        ost, want, n = dec.decode_packet(a, bpf)
+        assert ost == 0 and st[p] == 0 and ns[p] == n, (seed, p, ok.info[p], int(st[p]))
+        assert np.array_equal(out[p * fmt.packet_bytes:p * fmt.packet_bytes + n * bpf], want), (seed, p, ok.info[p])
+        if k:
+            assert np.array_equal(want, src), (seed, p, "forger / oracle round trip")

@@ -1,6 +1,8 @@
 """One-off soak of tests/test_gpu_fuzz.py's randomised parity case with seeds beyond the 48 the suite runs:
-    python tools/fuzz_soak.py FIRST LAST ["k=v,k=v"]    (GPU box; every seed: GPU packets == oracle packets, decode == input;
-                                                         the optional third argument pins context options, e.g. "thru=1")"""
+    python tools/fuzz_soak.py FIRST LAST ["k=v,k=v"] [foreign]
+                                    (GPU box; every seed: GPU packets == oracle packets, decode == input; the optional third
+                                     argument pins context options, e.g. "thru=1"; "foreign": the randomised FOREIGN-stream
+                                     decode case of tests/test_gpu_foreign.py instead — forged headers and cookies)"""
 import os
 import sys
 
@@ -22,6 +24,10 @@ def main():
                 ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         print("options", sys.argv[3], flush=True)
     case = fz.test_random_layouts_match_oracle_and_round_trip
+    if len(sys.argv) > 4 and sys.argv[4] == "foreign":
+        import test_gpu_foreign as ff
+        case = ff.test_random_foreign_streams
+        print("case: foreign streams", flush=True)
     case = getattr(case, "__wrapped__", case)
     bad = 0
     for seed in range(first, last):
