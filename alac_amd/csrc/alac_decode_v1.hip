@@ -158,6 +158,22 @@ __device__ __forceinline__ const uint32_t *dec_window(const DecV1Args &V, uint64
     return w < tailStart ? V.raw + w : V.tail + min(w - tailStart, (uint64_t)(kDecTailWords - 16));
 }
 
+// the same with the source known at compile time (the entropy lanes and k_dec_raw: the fused launch, whose entropy wave is the
+// launch's serial chain, must not pay a select per word for a mode it never uses)
+template <bool DIRECT>
+__device__ __forceinline__ uint32_t dec_word_t(const DecV1Args &V, uint64_t tailStart, uint64_t i)
+{
+    if constexpr (!DIRECT) return V.words[i];
+    const uint64_t t = min(i - tailStart, (uint64_t)(kDecTailWords - 1));
+    return __builtin_bswap32(i < tailStart ? V.raw[i] : V.tail[t]);
+}
+template <bool DIRECT>
+__device__ __forceinline__ const uint32_t *dec_window_t(const DecV1Args &V, uint64_t tailStart, uint64_t w)
+{
+    if constexpr (!DIRECT) return V.words + w;
+    return w < tailStart ? V.raw + w : V.tail + min(w - tailStart, (uint64_t)(kDecTailWords - 16));
+}
+
 // k_dec_tail (DIRECT): the end of the stream as dwords in the caller's byte order, zero-filled behind the last byte
 __global__ __launch_bounds__(kDecTailWords) void k_dec_tail(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets, uint32_t *tail)
 {
@@ -395,6 +411,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
 
 // ---- k_dec_raw: uncompressed (escape) elements are fixed-width fields, i.e. not serial at all: one thread per
 // sample-frame reads its fields straight from the staged words (codec/ALACDecoder.cu:697-727 / :856-896)
+template <bool DIRECT>
 __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_t first, uint32_t step)
 {
     const DecodeArgs &A = V.d;
@@ -403,7 +420,7 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
     const uint32_t ech = rec->elementChannels, n = rec->numSamples, w = A.bitDepth;
     const uint64_t off = A.offsets[p];
     const uint64_t bitBase = (off & 3) * 8 + rec->pad;
-    const uint64_t wbase = off >> 2, tailStart = dec_tail_start(V);
+    const uint64_t wbase = off >> 2, tailStart = DIRECT ? dec_tail_start(V) : 0;
     const uint64_t lastWord = V.capWords - 2 - (off >> 2);  // k_dec_header has checked the payload; never index past the stage
     int32_t *rowU = V.plane + (uint64_t)p * A.numChannels * A.frameSize;
     // pad2 (k_dec_header): a 16-bit stereo element into a stereo frame — the fields ARE the PCM (codec/ALACDecoder.cu:856-874),
@@ -424,8 +441,8 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
                 const uint64_t b = bitBase + ((uint64_t)(j < n ? j : 0) * ech + (c < ech ? c : 0)) * w;
                 const uint32_t i = (uint32_t)min((uint64_t)(b >> 5), lastWord);
                 shs[u][c] = (uint32_t)(b & 31);
-                hi[u][c] = dec_word(V, tailStart, wbase + i);
-                lo[u][c] = dec_word(V, tailStart, wbase + i + 1);
+                hi[u][c] = dec_word_t<DIRECT>(V, tailStart, wbase + i);
+                lo[u][c] = dec_word_t<DIRECT>(V, tailStart, wbase + i + 1);
             }
         }
 #pragma unroll
@@ -457,7 +474,11 @@ __global__ __launch_bounds__(256) void k_dec_raw(DecV1Args V)
 {
     const DecLists L = dec_lists(V);
     const uint32_t count = L.cnt[4];
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) raw_body(V, L.raw[i], threadIdx.x, blockDim.x);
+    if (V.raw) {  // wave-uniform
+        for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) raw_body<true>(V, L.raw[i], threadIdx.x, blockDim.x);
+    } else {
+        for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) raw_body<false>(V, L.raw[i], threadIdx.x, blockDim.x);
+    }
 }
 
 // per-lane state of the entropy kernel
@@ -481,7 +502,7 @@ struct EntLane {
 // packets: 4.1 ms with the stores, 2.8 ms without them).  Here a round only RECORDS (position, value) per symbol; the
 // stores are issued at the start of the next round, right after the wait, and have a whole round to complete.  A symbol
 // that was not decoded repeats the lane's previous pair (same value to the same address: harmless).
-template <bool PB40, bool PUB, bool WIDE = false, bool ZFILL = WIDE, bool LOCAL = false>
+template <bool PB40, bool PUB, bool WIDE = false, bool ZFILL = WIDE, bool LOCAL = false, bool DIRECT = false>
 __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, uint32_t *ringRow, uint64_t wordBase,
                                                uint32_t cur0, uint32_t bit0, uint32_t limit, uint64_t nbytes,
                                                uint32_t numSamples, uint32_t ech, uint32_t chanBits, uint32_t pbV,
@@ -490,15 +511,15 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
     const DecodeArgs &A = V.d;
     const uint32_t wb = (1u << A.kb) - 1;
     const uint64_t wordLimit = min(V.capWords, ((A.offsets[A.numPackets] + 3) >> 2) + 64);  // what k_dec_stage wrote
-    const uint64_t tailStart = dec_tail_start(V);
-    const bool swap = V.raw != nullptr;  // DIRECT: the caller's byte order
+    const uint64_t tailStart = DIRECT ? dec_tail_start(V) : 0;
+    constexpr bool swap = DIRECT;  // the caller's byte order
     auto fetch16 = [&](uint32_t rel, uint32_t (&q)[16]) {
         uint64_t w = wordBase + rel;
         const uint64_t lastStart = wordLimit - kWinWords;  // corrupt input may run past the packet: stay inside
         w = w < lastStart ? w : lastStart;
         // four 16-byte loads (the staged words are dword aligned only): a quarter of the L2 requests of sixteen dword loads
         typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
-        const U4 *sw = (const U4 *)dec_window(V, tailStart, w);
+        const U4 *sw = (const U4 *)dec_window_t<DIRECT>(V, tailStart, w);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const U4 t = sw[i];
@@ -747,7 +768,7 @@ __device__ __forceinline__ void entropy_rounds(EntLane &E, const DecV1Args &V, u
 }
 
 // PPW: packets per wave (lanes PPW .. 63 idle); progLds: LOCAL progress words of the workgroup, [PPW][2]
-template <bool PUB, bool WIDE = false, bool ZFILL = WIDE, int PPW = 64>
+template <bool PUB, bool WIDE = false, bool ZFILL = WIDE, int PPW = 64, bool DIRECT = false>
 __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring, uint32_t block, uint32_t *progLds = nullptr)
 {
     constexpr bool LOCAL = PPW != 64;
@@ -784,9 +805,9 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
         uint64_t w = wordBase + cur0;
         const uint64_t lastStart = wordLimit - kWinWords;
         w = w < lastStart ? w : lastStart;
-        const uint32_t *sw = dec_window(V, dec_tail_start(V), w);
+        const uint32_t *sw = dec_window_t<DIRECT>(V, DIRECT ? dec_tail_start(V) : 0, w);
 #pragma unroll
-        for (int i = 0; i < 16; i++) ringRow[i] = V.raw ? __builtin_bswap32(sw[i]) : sw[i];
+        for (int i = 0; i < 16; i++) ringRow[i] = DIRECT ? __builtin_bswap32(sw[i]) : sw[i];
     }
     asm volatile("" ::: "memory");
     // from here on word indices are relative to the first word staged (cur0): ring slot = index & 31 with no subtraction in
@@ -814,9 +835,9 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
 
     uint32_t *prog = (PUB && live) ? (LOCAL ? progLds + lane * 2 : V.prog + (uint64_t)p * 2) : nullptr;
     if (__all(!coded || (pbU == 40 && pbV == 40)))
-        entropy_rounds<true, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBaseR, 0u, bit0R, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<true, PUB, WIDE, ZFILL, LOCAL, DIRECT>(E, V, ringRow, wordBaseR, 0u, bit0R, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
     else
-        entropy_rounds<false, PUB, WIDE, ZFILL, LOCAL>(E, V, ringRow, wordBaseR, 0u, bit0R, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
+        entropy_rounds<false, PUB, WIDE, ZFILL, LOCAL, DIRECT>(E, V, ringRow, wordBaseR, 0u, bit0R, limit, nbytes, numSamples, ech, chanBits, pbV, prog);
 
     if (live && E.status != status0) {
         rec->status = E.status;
@@ -830,11 +851,14 @@ __device__ __forceinline__ void entropy_body(const DecV1Args &V, uint32_t *ring,
 // Four waves to a workgroup: a CU then takes the entropy waves four at a time, one per SIMD.  As single-wave workgroups
 // (about 7.6 per CU at 125 000 packets) some SIMD of a CU ended up with three of them, and the launch is as slow as that SIMD.
 constexpr int kEntWavesPerWg = 4;
+template <bool DIRECT>
 __global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_entropy_wide(DecV1Args V, uint32_t nEnt)
 {
     __shared__ uint32_t ring[kEntWavesPerWg][64 * kWinStride];
     const uint32_t slot = threadIdx.x >> 6, b = blockIdx.x * (uint32_t)kEntWavesPerWg + slot;
-    if (b < nEnt) entropy_body<false, true>(V, ring[slot], b);
+    if (b >= nEnt) return;
+    if constexpr (DIRECT) entropy_body<false, true, true, 64, true>(V, ring[slot], b);
+    else entropy_body<false, true>(V, ring[slot], b);
 }
 
 // ---- unpc_block (codec/dp_dec.c:55-381), in place over the chain's row ----
@@ -1443,7 +1467,7 @@ __global__ __launch_bounds__(256, 1) void k_dec_fused_wg(DecV1Args V, uint32_t n
             unpc_fast_body<true, kFusedPpw>(V, blockIdx.x * 3u + (slot - 1), progLds);
     } else {
         const uint32_t p = (blockIdx.x - nEnt) * 4u + slot;
-        if (p < V.d.numPackets) raw_body(V, p, threadIdx.x & 63, 64);
+        if (p < V.d.numPackets) raw_body<false>(V, p, threadIdx.x & 63, 64);
     }
 }
 
@@ -1734,7 +1758,10 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
         // paid only up to two entropy waves per SIMD; with the wide stores, measured whole decode pass at 125 000 / 250 000 /
         // 500 000 packets: 9.31 -> 8.19, 19.4 -> 14.2, 38.1 -> 26.5 ms — the kernel was bound by the number of store
         // instructions whose 64 lanes hit 64 different cache lines, which a CU's address path takes one line at a time)
-        hipLaunchKernelGGL(k_dec_entropy_wide, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
+        if (direct)
+            hipLaunchKernelGGL(k_dec_entropy_wide<true>, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
+        else
+            hipLaunchKernelGGL(k_dec_entropy_wide<false>, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
         // chains sorted by tap count, one lane per chain
         const dim3 ugrid(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg), ublock(64 * kEntWavesPerWg);
         if (da.bitDepth == 24) hipLaunchKernelGGL(k_dec_unpc_wide<24>, ugrid, ublock, 0, st, V);
