@@ -121,6 +121,29 @@ __device__ __forceinline__ void lms_push(Lms<NA> &s, int32_t x)
     s.h[0] = x;
 }
 
+// The coefficient walk of dp_enc.c:143-188 / dp_dec.c:131-181, in the reference's own terms: del0 shrinks (grows, for a negative
+// residual) by (NA - k) * ((+-sign(dd) * dd) >> denshift) tap by tap, and the walk STOPS for good the first time del0 has
+// changed sign.  (Rounds 1-3 evaluated "tap k is touched iff |del| - the partial sum is still positive" per tap, which is the
+// same thing while the partial sums only grow — and is not once they wrap: 32-bit mono material with a small denShift makes a
+// single term exceed 2^31, the remainder turns positive again and a later tap got an update the reference had already
+// broken out of.  Found by round 4's foreign-stream soak, seed 289.  The hot kernels have their own threshold forms and only
+// run where chanBits <= 23 and denShift = 9: no term can wrap there.)
+template <int NA>
+__device__ __forceinline__ void lms_adapt(Lms<NA> &s, const int32_t (&b)[NA], int32_t del, uint32_t denshift)
+{
+    const int32_t sg = sign_of(del);
+    int32_t del0 = del;
+    bool go = sg != 0;
+#pragma unroll
+    for (int k = NA - 1; k >= 0; k--) {
+        const int32_t sgn = sign_of(b[k]);           // b[k] = top - in[j - 1 - k] = dd
+        const int32_t step = wmul(sg, sgn);          // sg > 0: coefs[k] -= sgn; sg < 0: coefs[k] += sgn
+        s.a[k] = (int16_t)(s.a[k] - (go ? step : 0));
+        del0 = wsub(del0, wmul(NA - k, wmul(step, b[k]) >> denshift));
+        go = go && (sg > 0 ? del0 > 0 : del0 < 0);
+    }
+}
+
 // One encoder step for j > NA: returns the residual and adapts the coefficients (sign-LMS).
 // The early-exit update loop of dp_enc.c:143-188 is evaluated branch-free: with E = |del| and
 // t_k = (|b_k| + (del < 0 ? 511 : 0)) >> 9  [ (sgn*b)>>9 resp. -((-sgn*b)>>9) ], tap k is
@@ -137,16 +160,7 @@ __device__ __forceinline__ int32_t lms_step_enc(Lms<NA> &s, int32_t x, uint32_t 
         sum = wadd(sum, wmul(s.a[k], b[k]));
     }
     int32_t del = sext(wsub(wsub(x, top), wsub(1 << (kDenShift - 1), sum) >> kDenShift), chanshift);
-
-    const int32_t sgd = (del > 0) - (del < 0);
-    int32_t e = wabs(del);
-    const int32_t off = del < 0 ? 511 : 0;
-#pragma unroll
-    for (int k = NA - 1; k >= 0; k--) {
-        const int32_t d = (e > 0) ? sgd * sign_of(b[k]) : 0;
-        s.a[k] = (int16_t)(s.a[k] - d);
-        e = wsub(e, wmul(NA - k, wadd(wabs(b[k]), off) >> kDenShift));
-    }
+    lms_adapt<NA>(s, b, del, kDenShift);
     lms_push<NA>(s, x);
     return del;
 }
@@ -167,16 +181,7 @@ __device__ __forceinline__ int32_t lms_step_dec(Lms<NA> &s, int32_t del, uint32_
     }
     const int32_t denhalf = denshift ? (1 << (denshift - 1)) : 0;
     const int32_t out = sext(wadd(wadd(del, top), wsub(denhalf, sum) >> denshift), chanshift);
-
-    const int32_t sgd = (del > 0) - (del < 0);
-    int32_t e = wabs(del);
-    const int32_t off = del < 0 ? ((1 << denshift) - 1) : 0;
-#pragma unroll
-    for (int k = NA - 1; k >= 0; k--) {
-        const int32_t d = (e > 0) ? sgd * sign_of(b[k]) : 0;
-        s.a[k] = (int16_t)(s.a[k] - d);
-        e = wsub(e, wmul(NA - k, wadd(wabs(b[k]), off) >> denshift));
-    }
+    lms_adapt<NA>(s, b, del, denshift);
     lms_push<NA>(s, out);
     return out;
 }

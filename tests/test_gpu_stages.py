@@ -97,7 +97,10 @@ def test_wide_full_scale_samples_wrap_like_the_reference(gpu_ctx, oracle, chanbi
     import torch
     rng = np.random.default_rng(chanbits)
     lim = (1 << (chanbits - 1)) - 1
-    for na, ds in ((4, 9), (8, 9), (8, 5), (4, 12), (1, 12), (6, 5), (16, 7), (30, 4), (31, 9), (0, 9), (2, 1), (12, 15)):
+    # (small shifts with 4 / 8 taps: one term of the coefficient walk exceeds 2^31 at chanBits 32 and del0 wraps — the walk must
+    # still stop where the reference's stops, foreign-stream soak seed 289)
+    for na, ds in ((4, 9), (8, 9), (8, 5), (4, 12), (1, 12), (6, 5), (16, 7), (30, 4), (31, 9), (0, 9), (2, 1), (12, 15), (8, 4),
+                   (8, 1), (4, 3), (4, 1), (8, 2)):
         rows, num = 4, 200
         x = rng.integers(-lim - 1, lim + 1, size=(rows, num + 40)).astype(np.int32)
         x[1] //= 3

@@ -110,7 +110,7 @@ def test_stages_match_reference_objects_at_foreign_parameters(oracle, ref):
     rng = np.random.default_rng(20261005)
     for trial in range(400):
         na = int(rng.integers(0, 32))
-        cb = int(rng.choice([9, 16, 17, 20, 21, 24, 25]))
+        cb = int(rng.choice([9, 16, 17, 20, 21, 24, 25, 32]))  # 32: full-scale differences and walk terms wrap (int32)
         ds = int(rng.integers(1, 16))
         num = int(rng.choice([1, 2, 5, 12, 33, 128, 400]))
         amp = int(rng.choice([3, 500, 30000, 1 << (cb - 1)]))
