@@ -335,7 +335,7 @@ DecLayout dec_layout(const alac_hip_format *f, uint32_t numPackets, uint64_t str
     L.resid = off;
     off = align_up(off + (uint64_t)f->num_channels * f->frame_size * numPackets * 4 + 256, 256);  // + block over-read
     L.prog = off;  // progress words of the fused launch / chain list, counters and pair list of the separate launches
-    off = align_up(off + (uint64_t)numPackets * 20 + 64, 256);  // dec_lists (alac_decode_v1.hip): 5 n words + 16 counters
+    off = align_up(off + (uint64_t)numPackets * 28 + 64, 256);  // dec_lists (alac_decode_v1.hip): 7 n words + 16 counters
     L.elemBit = off;
     off = align_up(off + (uint64_t)numPackets * 4, 256);
     L.mismatch = off;

@@ -198,6 +198,8 @@ __global__ __launch_bounds__(kDecTailWords) void k_dec_tail(const uint8_t *strea
 constexpr uint32_t kDecCounters = 16;
 struct DecLists {
     uint32_t *chains, *cnt, *pairs, *raw, *rest;
+    uint32_t *any;   // [2n] chains of mode 0 with 1..8 taps and any denShift that are neither 4- nor 8-tap / denShift-9 chains:
+                     // what OTHER encoders emit (ffmpeg: orders 4..6, a shift per frame) — unpc_any_body, counter 6
 };
 __device__ __host__ inline DecLists dec_lists(const DecV1Args &V)
 {
@@ -208,6 +210,7 @@ __device__ __host__ inline DecLists dec_lists(const DecV1Args &V)
     L.pairs = L.cnt + kDecCounters;
     L.raw = L.pairs + n;
     L.rest = L.raw + n;
+    L.any = L.rest + n;
     return L;
 }
 // Pair mode (16-bit stereo into a stereo frame, the shape of the benchmark and of most files): a packet whose two chains
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     int32_t status = (live && V.round > 0) ? A.statusOut[p] : 0;  // a packet that failed in an earlier round stays failed
     uint32_t pbU = A.pb, pbV = A.pb;
     bool okc[2] = {false, false}, widec[2] = {false, false};  // chain c passes unpc_fast_ok's header part / has 8 taps
+    bool anyc[2] = {false, false};                            // ... or unpc_any_ok's: mode 0, 1..8 taps, denShift 1..15
     DecRec R;
     R.numSamples = 0;
     R.escape = 0;
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                         rec->c[c].num = (uint16_t)(b & 0x1f);
                         okc[c] = rec->c[c].mode == 0 && rec->c[c].denShift == kDenShift && ((b & 0x1f) == 4 || (b & 0x1f) == 8);
                         widec[c] = (b & 0x1f) == 8;
+                        anyc[c] = !okc[c] && rec->c[c].mode == 0 && (b & 0x1f) >= 1 && (b & 0x1f) <= 8 && rec->c[c].denShift >= 1;
                         if (c == 0) pbU = (A.pb * (b >> 5)) / 4;  // :825
                         else pbV = (A.pb * (b >> 5)) / 4;        // :841
                         for (uint32_t i = 0; i < (b & 0x1f); i++)
@@ -402,6 +407,8 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
         push(ok1 && !pair && wide1, 1, L.chains, p * A.numChannels + 1, true, total);
         push(pair && !wide0 && !wide1, 2, L.pairs, p, false, A.numPackets);
         push(pair && (wide0 || wide1), 3, L.pairs, p, true, A.numPackets);
+        push(good && fastShape && anyc[0], 6, L.any, p * A.numChannels, false, total);
+        push(good && fastShape && R.elementChannels == 2 && anyc[1], 6, L.any, p * A.numChannels + 1, false, total);
         push(rawP, 4, L.raw, p, false, A.numPackets);
         push(good && !pair && !rawDirect, 5, L.rest, p, false, A.numPackets);
     }
@@ -875,6 +882,17 @@ __device__ __forceinline__ bool unpc_fast_ok(const DecodeArgs &A, const DecRec *
            (c.num == 4 || c.num == 8) && chanBits <= kFastChanBits;
 }
 
+// chains the separate launches hand to unpc_any_body (the same test as k_dec_header's anyc && fastShape)
+__device__ __forceinline__ bool unpc_any_ok(const DecodeArgs &A, const DecRec *rec, uint32_t ch)
+{
+    if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return false;
+    const DecChan &c = rec->c[ch];
+    const uint32_t chanBits = A.bitDepth - rec->bytesShifted * 8 + (rec->elementChannels == 2 ? 1 : 0);
+    const bool fast = c.mode == 0 && c.denShift == kDenShift && (c.num == 4 || c.num == 8);
+    return (A.frameSize & 7) == 0 && rec->numSamples >= 16 && chanBits <= kFastChanBits && !fast && c.mode == 0 && c.num >= 1 &&
+           c.num <= 8 && c.denShift >= 1;
+}
+
 // the first 16 samples (warm-up positions + a few regular steps), lane-serial; leaves coefficients and outputs
 template <int NA>
 __device__ __forceinline__ void unpc_head16(const int32_t (&del)[16], int32_t (&out)[16], int32_t (&a8)[8],
@@ -1212,6 +1230,167 @@ __device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, CoopTile &S, 
     }
 }
 
+// ---- any tap count 1..8, any denShift 1..15, mode 0 (round 4): the chains of OTHER encoders' streams on the one-lane mapping.
+// An 8-tap lane with the lane's own count na: taps i >= na are dead (coefficient 0, sign forced to 0: t_i = 0, nothing is ever
+// added), the "top" sample is w[na - 1] as it leaves the window (an 8-way select: the compiler keeps the eight lane masks in
+// scalar registers), the threshold weights are na - i, the shifts and the rounding are the lane's denShift.  No term of the
+// walk can wrap: chanBits <= 23 (k_dec_header), so |b| < 2^23 and sum_i (na - i) ((|b_i| + rc) >> ds) < 2^29.
+struct AnyLane {
+    int32_t na, ds, denhalf, rcMask;
+    int32_t am[8];    // -1 for live taps
+    uint32_t wg[8];   // na - i (0 for dead taps)
+};
+__device__ __forceinline__ int32_t lms_step_dec_any(int32_t (&a)[8], int32_t (&w)[8], int32_t &tp, int32_t del, uint32_t chanbits,
+                                                    const AnyLane &L)
+{
+    int32_t b[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = tp - w[i];
+    int32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s = __mul24((int32_t)(int16_t)a[i], b[i]) + s;  // (dead taps: a = 0)
+    const int32_t out = __builtin_amdgcn_sbfe(del + tp + ((L.denhalf - s) >> L.ds), 0, chanbits);
+    const int32_t nd = -del;
+    const int32_t adel = max(del, nd);
+    const int32_t nsg = sign3(nd);
+    const int32_t rc = (del >> 31) & L.rcMask;
+    int32_t sb[8];
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        sb[i] = sign3(b[i]) & L.am[i];
+        t[i] = (uint32_t)(__mul24(sb[i], b[i]) + rc) >> L.ds;
+    }
+    int32_t S[8];
+    S[7] = 0;
+#pragma unroll
+    for (int i = 7; i > 0; i--) S[i - 1] = (int32_t)__umul24(t[i], L.wg[i]) + S[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = __mul24(adel > S[i] ? nsg : 0, sb[i]) + a[i];
+    int32_t leaving = w[0];
+#pragma unroll
+    for (int i = 1; i < 8; i++) leaving = (L.na - 1 == i) ? w[i] : leaving;
+    tp = leaving;
+#pragma unroll
+    for (int i = 7; i > 0; i--) w[i] = w[i - 1];
+    w[0] = out;
+    return out;
+}
+
+__device__ __forceinline__ void unpc_any_body(const DecV1Args &V, CoopTile &S, uint32_t block, uint32_t count)
+{
+    const DecodeArgs &A = V.d;
+    if (block * 64u >= count) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t idx = block * 64u + lane;
+    const bool active = idx < count;
+    const uint32_t chain = active ? dec_lists(V).any[idx] : 0;
+    const uint32_t p = chain / A.numChannels, ch = chain % A.numChannels;
+    const DecRec *rec = A.recs + p;
+    const uint32_t n = active ? rec->numSamples : 0;
+    const uint32_t chanbits = A.bitDepth - (active ? rec->bytesShifted : 0) * 8 + ((active ? rec->elementChannels : 1) == 2 ? 1 : 0);
+    int32_t *row = V.plane + (uint64_t)chain * A.frameSize;
+    AnyLane L;
+    L.na = active ? (int32_t)rec->c[ch].num : 1;
+    L.ds = active ? (int32_t)rec->c[ch].denShift : 9;
+    L.denhalf = 1 << (L.ds - 1);
+    L.rcMask = (1 << L.ds) - 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        L.am[i] = i < L.na ? -1 : 0;
+        L.wg[i] = i < L.na ? (uint32_t)(L.na - i) : 0u;
+    }
+    int32_t a[8], w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a[i] = (active && i < L.na) ? (int32_t)rec->c[ch].coefs[i] : 0;
+        w[i] = 0;
+    }
+    int32_t tp = 0;
+    // ---- the first 16 samples: position 0 as it comes, positions 1 .. na first-order (codec/dp_dec.c:97-101), then regular steps;
+    // both forms are evaluated and selected per lane (16 steps, once per chain)
+    {
+        int32_t d[16], o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int4 t = active ? ((const int4 *)row)[q] : make_int4(0, 0, 0, 0);
+            d[4 * q] = t.x;
+            d[4 * q + 1] = t.y;
+            d[4 * q + 2] = t.z;
+            d[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j == 0) {
+                o[0] = d[0];
+                w[0] = o[0];
+            } else {
+                // warm-up form: the window shifts, nothing adapts; regular form: the full step.  Both from the same state.
+                int32_t a2[8], w2[8], tp2 = tp;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    a2[i] = a[i];
+                    w2[i] = w[i];
+                }
+                const int32_t reg = lms_step_dec_any(a2, w2, tp2, d[j], chanbits, L);
+                const int32_t warm = __builtin_amdgcn_sbfe(d[j] + w[0], 0, chanbits);
+                const bool isWarm = j <= L.na;
+                int32_t leaving = w[0];
+#pragma unroll
+                for (int i = 1; i < 8; i++) leaving = (L.na - 1 == i) ? w[i] : leaving;
+                o[j] = isWarm ? warm : reg;
+#pragma unroll
+                for (int i = 0; i < 8; i++) a[i] = isWarm ? a[i] : a2[i];
+#pragma unroll
+                for (int i = 7; i > 0; i--) w[i] = w[i - 1];
+                w[0] = o[j];
+                tp = leaving;  // (the regular step leaves the same sample: w_old[na - 1])
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (4u * q < n) ((int4 *)row)[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        }
+    }
+    const uint32_t nMax = wave_max_u32(n);
+    S.rowOf[lane] = row;
+    asm volatile("" ::: "memory");
+    CoopRegs tA, tB;
+    if (32 < nMax) coop_load(S, lane, 32, tA);
+    if (16 < nMax) {
+        int32_t d[16], o[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int4 t = *(const int4 *)(row + 16 + 4 * q);
+            d[4 * q] = t.x;
+            d[4 * q + 1] = t.y;
+            d[4 * q + 2] = t.z;
+            d[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) o[s2] = lms_step_dec_any(a, w, tp, d[s2], chanbits, L);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (active && 16 + 4 * q < n) *(int4 *)(row + 16 + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+    auto step32 = [&](uint32_t jb, const CoopRegs &curT, CoopRegs &nxtT) {
+        int32_t cur[32];
+        coop_take(S, lane, curT, cur);
+        if (jb + 32 < nMax) coop_load(S, lane, jb + 32, nxtT);
+        int32_t o[32];
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) o[s2] = lms_step_dec_any(a, w, tp, cur[s2], chanbits, L);
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (active && jb + 4 * q < n) *(int4 *)(row + jb + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    };
+    for (uint32_t jb = 32; jb < nMax; jb += 64) {
+        step32(jb, tA, tB);
+        if (jb + 32 < nMax) step32(jb + 32, tB, tA);
+    }
+}
+
 // ---- pair mode: the two chains of a stereo packet in adjacent lanes; the lanes un-mix and write the PCM themselves ----
 // T = 4: both chains have 4 taps.  T = 8: at least one has 8; a 4-tap chain then lives in an 8-tap lane with dead upper
 // taps: their coefficients start at 0 and stay there (the sign of b is forced to 0, so t = 0 and nothing is added), the
@@ -1469,8 +1648,8 @@ __global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_unpc_wide(DecV1Args
     __shared__ CoopTile tiles[kEntWavesPerWg];
     CoopTile &S = tiles[threadIdx.x >> 6];
     const uint32_t *cnt = dec_lists(V).cnt;
-    const uint32_t c4 = cnt[0], c8 = cnt[1], pA = cnt[2], pB = cnt[3];
-    const uint32_t nbB = (pB + 31u) / 32u, nb8 = (c8 + 63u) / 64u, nbA = (pA + 31u) / 32u;
+    const uint32_t c4 = cnt[0], c8 = cnt[1], pA = cnt[2], pB = cnt[3], cAny = cnt[6];
+    const uint32_t nbB = (pB + 31u) / 32u, nb8 = (c8 + 63u) / 64u, nbA = (pA + 31u) / 32u, nb4 = (c4 + 63u) / 64u;
     uint32_t b = blockIdx.x * (uint32_t)kEntWavesPerWg + (threadIdx.x >> 6);
     if (b < nbB) return unpc_pair_body<8, DEPTH>(V, S, b, pB);
     b -= nbB;
@@ -1478,7 +1657,9 @@ __global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_unpc_wide(DecV1Args
     b -= nb8;
     if (b < nbA) return unpc_pair_body<4, DEPTH>(V, S, b, pA);
     b -= nbA;
-    unpc_wide_body<4>(V, S, b, c4);
+    if (b < nb4) return unpc_wide_body<4>(V, S, b, c4);
+    b -= nb4;
+    unpc_any_body(V, S, b, cAny);  // other encoders' chains (none in a stream of this library's or Apple's encoder)
 }
 
 // ---- fused launch: the followers of an entropy wave are waves of ITS workgroup.  A workgroup = the entropy
@@ -1515,7 +1696,8 @@ __global__ __launch_bounds__(64) void k_dec_unpc(DecV1Args V)
     const uint32_t p = (uint32_t)(gid / A.numChannels), ch = (uint32_t)(gid % A.numChannels);
     const DecRec *rec = A.recs + p;
     if (rec->status != 0 || rec->escape || rec->elementChannels == 0) return;
-    if (unpc_fast_ok(A, rec, ch)) return;  // k_dec_unpc_fast's
+    if (unpc_fast_ok(A, rec, ch)) return;  // the fast predictor bodies'
+    if (V.lists && unpc_any_ok(A, rec, ch)) return;  // unpc_any_body's (separate launches)
     const uint32_t chanbits = A.bitDepth - rec->bytesShifted * 8 + (rec->elementChannels == 2 ? 1 : 0);
     int32_t *row = V.plane + ((uint64_t)p * A.numChannels + ch) * A.frameSize;
     const DecChan &c = rec->c[ch];
@@ -1799,7 +1981,8 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
         else
             hipLaunchKernelGGL(k_dec_entropy_wide<false>, dim3((nEnt + kEntWavesPerWg - 1) / kEntWavesPerWg), dim3(64 * kEntWavesPerWg), 0, st, V, nEnt);
         // chains sorted by tap count, one lane per chain
-        const dim3 ugrid(((uint32_t)((lanes + 63) / 64) + 4 + kEntWavesPerWg - 1) / kEntWavesPerWg), ublock(64 * kEntWavesPerWg);
+        // (five lists, each rounded up to whole waves)
+        const dim3 ugrid(((uint32_t)((lanes + 63) / 64) + 6 + kEntWavesPerWg - 1) / kEntWavesPerWg), ublock(64 * kEntWavesPerWg);
         if (da.bitDepth == 24) hipLaunchKernelGGL(k_dec_unpc_wide<24>, ugrid, ublock, 0, st, V);
         else if (da.bitDepth == 20) hipLaunchKernelGGL(k_dec_unpc_wide<20>, ugrid, ublock, 0, st, V);
         else hipLaunchKernelGGL(k_dec_unpc_wide<16>, ugrid, ublock, 0, st, V);

@@ -168,3 +168,38 @@ def test_random_foreign_streams(gpu_ctx, oracle, seed):
         assert np.array_equal(out[p * fmt.packet_bytes:p * fmt.packet_bytes + n * bpf], want), (seed, p, ok.info[p])
         if k:
             assert np.array_equal(want, src), (seed, p, "forger / oracle round trip")
+
+
+@pytest.mark.parametrize("depth,channels", [(16, 2), (16, 1), (24, 2)])
+def test_a_whole_batch_from_another_encoder(gpu_ctx, oracle, depth, channels):
+    """34 000 packets (the separate-launch regime) ALL shaped like another encoder's: mode 0, prediction orders 1..8 and a
+    denominator shift per packet (what ffmpeg's encoder writes: orders 4..6, a shift per frame), pbFactor 4 — the chains of
+    the one-lane predictor for any tap count up to 8 (unpc_any_body); every packet against the oracle, and against the source"""
+    frame, n = 128, 34000
+    rng = np.random.default_rng(31 + depth + channels)
+    f = forge.Forger(oracle)
+    pk, src = [], []
+    for i in range(n):
+        kind = int(rng.integers(0, 5))
+        pcm = forge.test_signal(rng, kind, frame, depth, channels, headroom_bits=1)
+        params = []
+        for _ in range(channels):
+            num, den = int(rng.choice([1, 2, 3, 4, 5, 6, 6, 7, 8])), int(rng.choice([4, 5, 6, 7, 8, 9, 9, 10]))
+            cp = forge.ChannelParams(num, den, 4, 0)
+            cp.coefs[:num] = rng.integers(-(1 << den), (1 << den) + 1, size=num) if i % 3 else forge.default_coefs(num, den)[:num]
+            params.append(cp)
+        shifted = 1 if depth == 24 else 0
+        pk.append(f.element(pcm, frame, depth, channels, frame, params, mix_bits=2, mix_res=int(rng.integers(0, 5)) if channels == 2 else 0,
+                            bytes_shifted=shifted))
+        src.append(pcm)
+    ck = forge.cookie(frame, depth, channels)
+    out, ns, st, fmt = gpu_decode(gpu_ctx, ck, pk)
+    assert int(np.abs(st).sum()) == 0 and (ns == frame).all()
+    got = out.reshape(n, fmt.packet_bytes)
+    want = np.stack([np.frombuffer(bytes(x), np.uint8) for x in src])
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (bad[:8].tolist())
+    dec = oracle.decoder(ck)
+    for p in range(0, n, 499):
+        ost, w, m = dec.decode_packet(pk[p], fmt.bytes_per_frame)
+        assert ost == 0 and np.array_equal(w, want[p])
