@@ -42,7 +42,7 @@ int32_t alacfile_sniff(const uint8_t *file, uint64_t size, alacfile_info *out, c
 
 static uint64_t give(const Bytes &b, uint8_t *out, uint64_t cap)
 {
-    if (out && b.size() <= cap) memcpy(out, b.data(), b.size());
+    if (out && !b.empty() && b.size() <= cap) memcpy(out, b.data(), b.size());
     return b.size();
 }
 
@@ -89,7 +89,7 @@ int64_t alacfile_parse_stsd(const uint8_t *box, uint64_t size, uint8_t *cookie_o
     Bytes ck;
     if (!parse_alac_sample_description(Bytes(box, box + size), ck, fields3[0], fields3[1], fields3[2]).empty() || ck.size() > 64)
         return -1;
-    memcpy(cookie_out, ck.data(), ck.size());
+    if (!ck.empty()) memcpy(cookie_out, ck.data(), ck.size());
     return (int64_t)ck.size();
 }
 
@@ -103,7 +103,7 @@ int64_t alacfile_parse_alac_caf(const uint8_t *file, uint64_t size, uint8_t *coo
     AlacCafContents c;
     if (!parse_alac_caf(f, info, c).empty()) return -1;
     *cookie_size = (uint32_t)c.cookie.size();
-    if (c.cookie.size() <= 64) memcpy(cookie_out, c.cookie.data(), c.cookie.size());
+    if (!c.cookie.empty() && c.cookie.size() <= 64) memcpy(cookie_out, c.cookie.data(), c.cookie.size());
     for (size_t i = 0; i < c.packetBytes.size() && i < max_packets; i++) sizes_out[i] = c.packetBytes[i];
     *data_pos = c.dataPos;
     return (int64_t)c.packetBytes.size();
@@ -146,7 +146,7 @@ int64_t alacfile_parse_alac_m4a(const uint8_t *file, uint64_t size, alacfile_inf
     info_out->data_pos = info.dataPos;
     info_out->data_size = info.dataSize;
     *cookie_size = (uint32_t)c.cookie.size();
-    if (c.cookie.size() <= 64) memcpy(cookie_out, c.cookie.data(), c.cookie.size());
+    if (!c.cookie.empty() && c.cookie.size() <= 64) memcpy(cookie_out, c.cookie.data(), c.cookie.size());
     for (size_t i = 0; i < c.packetBytes.size() && i < max_packets; i++) {
         sizes_out[i] = c.packetBytes[i];
         pos_out[i] = c.packetPos[i];
