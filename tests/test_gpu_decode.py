@@ -345,3 +345,75 @@ def test_decode_through_wrapped_cookies(gpu_ctx, oracle, channels):
         assert (f2.frame_size, f2.bit_depth, f2.num_channels, f2.sample_rate) == (4096, 16, channels, 44100)
         assert int(st.abs().sum()) == 0 and int(ns.sum()) == n * 4096
         assert np.array_equal(out.cpu().numpy(), pcm)
+
+
+def _escape_overrun(pkt, depth, channels, frame):
+    """is this a packet whose first element is UNCOMPRESSED and whose fixed-width payload ends past the packet?  (The reference
+    reads such a payload past the end of its buffer and reports no error; this library refuses it: documented local hardening.)"""
+    bits = np.unpackbits(np.ascontiguousarray(pkt, np.uint8))
+    if bits.size < 23:
+        return False
+    val = lambda a, n: int("".join(map(str, bits[a:a + n])), 2) if a + n <= bits.size else 0  # noqa: E731
+    tag = val(0, 3)
+    if tag not in (0, 1, 3) or val(7, 12) != 0:
+        return False
+    hb = val(19, 4)
+    if not (hb & 1):
+        return False
+    pos, n = 23, frame
+    if hb >> 3:
+        n = val(pos, 32)
+        pos += 32
+    ech = 2 if tag == 1 else 1
+    return pos + n * ech * depth > bits.size
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_corrupt_packets_differential(gpu_ctx, oracle, block):
+    """truncated, bit-flipped, overwritten and over-long packets (640 per block, five depths, mono / stereo, six frame sizes),
+    GPU against the oracle: nothing faults or hangs; wherever both accept a packet the PCM is identical; the ONLY status
+    differences are packets with an uncompressed element cut short, which the reference decodes from whatever lies behind its
+    buffer (codec/ALACDecoder.cu:697-727, :856-896 read without a bounds test) and this library refuses with kALAC_ParamError"""
+    import torch
+    both0 = 0
+    for seed in range(block * 10, block * 10 + 10):
+        rng = np.random.default_rng(90000 + seed)
+        depth = int(rng.choice([16, 16, 24, 20, 32]))
+        channels = int(rng.choice([1, 2, 2]))
+        frame = int(rng.choice([4096, 1024, 512, 100, 64, 2048]))
+        fmt = alac_amd.make_format(frame, depth, channels)
+        n = 64
+        pcm = alac_amd.synth_pcm(seed * 64, n, fmt)
+        enc = oracle.encoder(frame, depth, channels)
+        pk = []
+        for p in range(n):
+            enc.reset()
+            a = enc.encode_packet(pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes], frame).copy()
+            kind = int(rng.integers(0, 6))
+            if kind == 0:
+                a = a[:int(rng.integers(1, len(a) + 1))]
+            elif kind in (1, 2):
+                for _ in range(int(rng.integers(1, 4))):
+                    a[int(rng.integers(0, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 3:
+                a[int(rng.integers(0, min(len(a), 24)))] = int(rng.integers(0, 256))
+            elif kind == 4:
+                a = np.concatenate([a, rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)])
+            pk.append(a)
+        ck = enc.cookie()
+        stream = np.concatenate(pk)
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in pk])]).astype(np.int64)
+        out, ns, st, _ = gpu_ctx.decode(ck, torch.from_numpy(stream).cuda(), torch.from_numpy(offs).cuda(), n)
+        gpu_ctx.synchronize()
+        out, ns, st = out.cpu().numpy(), ns.cpu().numpy(), st.cpu().numpy()
+        dec = oracle.decoder(ck)
+        bpf = fmt.bytes_per_frame
+        for p in range(n):
+            ost, want, m = dec.decode_packet(pk[p], bpf)
+            assert st[p] in (0, -50, -4), (seed, p, int(st[p]))
+            if (ost == 0) != (st[p] == 0):
+                assert ost == 0 and st[p] == -50 and _escape_overrun(pk[p], depth, channels, frame), (seed, p, ost, int(st[p]), len(pk[p]))
+            elif ost == 0:
+                both0 += 1
+                assert ns[p] == m and np.array_equal(out[p * fmt.packet_bytes:p * fmt.packet_bytes + m * bpf], want), (seed, p)
+    assert both0 > 300
