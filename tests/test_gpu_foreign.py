@@ -172,10 +172,11 @@ def test_random_foreign_streams(gpu_ctx, oracle, seed):
 
 @pytest.mark.parametrize("depth,channels", [(16, 2), (16, 1), (24, 2)])
 def test_a_whole_batch_from_another_encoder(gpu_ctx, oracle, depth, channels):
-    """34 000 packets (the separate-launch regime) ALL shaped like another encoder's: mode 0, prediction orders 1..8 and a
-    denominator shift per packet (what ffmpeg's encoder writes: orders 4..6, a shift per frame), pbFactor 4 — the chains of
-    the one-lane predictor for any tap count up to 8 (unpc_any_body); every packet against the oracle, and against the source"""
-    frame, n = 128, 34000
+    """6 000 packets ALL shaped like another encoder's: mode 0, prediction orders 1..8 and a denominator shift per packet (what
+    ffmpeg's encoder writes: orders 4..6, a shift per frame), pbFactor 4 — through the separate launches (dec_fused = 0: the
+    regime of large batches), where such chains take the one-lane predictor for any tap count up to 8 (unpc_any_body); every
+    packet against the source, a sample against the oracle"""
+    frame, n = 128, 6000
     rng = np.random.default_rng(31 + depth + channels)
     f = forge.Forger(oracle)
     pk, src = [], []
@@ -193,7 +194,8 @@ def test_a_whole_batch_from_another_encoder(gpu_ctx, oracle, depth, channels):
                             bytes_shifted=shifted))
         src.append(pcm)
     ck = forge.cookie(frame, depth, channels)
-    out, ns, st, fmt = gpu_decode(gpu_ctx, ck, pk)
+    with gpu_ctx.options(dec_fused=0):
+        out, ns, st, fmt = gpu_decode(gpu_ctx, ck, pk)
     assert int(np.abs(st).sum()) == 0 and (ns == frame).all()
     got = out.reshape(n, fmt.packet_bytes)
     want = np.stack([np.frombuffer(bytes(x), np.uint8) for x in src])
