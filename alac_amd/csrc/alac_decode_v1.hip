@@ -1098,51 +1098,32 @@ __device__ __forceinline__ int32_t lms_step_dec_wide(int32_t (&a)[T], int32_t (&
     return out;
 }
 
-// ---- cooperative residual fetch of the one-lane-per-chain predictors (round 4) ----
-// A lane's chain is a 16 KB row of the plane; a lane that streams through ITS row with 16-byte loads makes a wave's load
-// instruction touch 64 different lines, and every line is asked for eight times, a block apart: tools/fetch_calibrate.hip
-// measured that shape fetching each line 2.25 times at 1.5 TB/s.  Here the eight loads of a 32-step block are dealt the other
-// way round: instruction q fetches, for lane L, 16 bytes of the row of lane 8 q + L / 8 — eight neighbouring lanes cover one
-// whole 128-byte line, eight lines per instruction, every line asked for once — and the block is transposed through LDS
-// (one ds_write_b128 / ds_read_b128 pair per load; a wave's LDS operations execute in order, no barrier).  The loads of block
-// i + 1 are in flight, in registers, while block i computes, as before.
-constexpr int kTileStride = 36;  // dwords per row of the transpose tile: 32 + 4 (16-byte aligned, conflict-free b128 columns)
-struct CoopTile {
-    int32_t tile[64 * kTileStride];
-    int32_t *rowOf[64];
-};
-typedef int32_t CoopRegs[8][4];
-__device__ __forceinline__ void coop_load(const CoopTile &S, uint32_t lane, uint32_t jb, CoopRegs &t)
+// ---- residual blocks of the one-lane-per-chain predictors ----
+// 32-step blocks = one 128-byte line of the lane's row: the eight 16-byte loads of a block are issued back to back, so the
+// line is fetched from L2 once (with two loads per 8 steps the line had left the L1 — 10 waves x 64 rows — before its next
+// quarter was wanted: four L2 requests per line).  The residuals of block i + 1 are loaded while block i computes.
+// (Round 4 also built a COOPERATIVE form — instruction q fetches, for lane L, 16 bytes of the row of lane 8 q + L / 8, so that
+// eight neighbouring lanes cover one whole line, and the block is transposed through LDS — because tools/fetch_calibrate.hip
+// shows a lane streaming through its own row with ONE 16-byte load per iteration fetching every line 2.25 times.  It changed
+// nothing: 5.13 -> 5.14 ms at 125 000 packets and FETCH_SIZE of k_dec_unpc_wide 1.839 -> 1.835 GB for 3.6 GB of distinct rows —
+// with the eight loads back to back the lines already arrive as whole 128-byte requests, once each, and the kernel issues at
+// the chip's instruction ceiling.  Removed.)
+__device__ __forceinline__ void load32(const int32_t *row, uint32_t jb, int32_t (&d)[32])
 {
+    // rows are frameSize long and the plane is padded by 256 bytes: the (unused) over-read of the last block, at most
+    // 31 samples past the longest row, stays inside
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const int4 v = *(const int4 *)(S.rowOf[q * 8 + (lane >> 3)] + jb + 4 * (lane & 7));
-        t[q][0] = v.x;
-        t[q][1] = v.y;
-        t[q][2] = v.z;
-        t[q][3] = v.w;
+        const int4 t = *(const int4 *)(row + jb + 4 * q);
+        d[4 * q] = t.x;
+        d[4 * q + 1] = t.y;
+        d[4 * q + 2] = t.z;
+        d[4 * q + 3] = t.w;
     }
-}
-__device__ __forceinline__ void coop_take(CoopTile &S, uint32_t lane, const CoopRegs &t, int32_t (&d)[32])
-{
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-        *(int4 *)(S.tile + (q * 8 + (lane >> 3)) * kTileStride + 4 * (lane & 7)) = make_int4(t[q][0], t[q][1], t[q][2], t[q][3]);
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int4 v = *(const int4 *)(S.tile + lane * kTileStride + 4 * q);
-        d[4 * q] = v.x;
-        d[4 * q + 1] = v.y;
-        d[4 * q + 2] = v.z;
-        d[4 * q + 3] = v.w;
-    }
-    asm volatile("" ::: "memory");
 }
 
 template <int T>
-__device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, CoopTile &S, uint32_t block, uint32_t count)
+__device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, uint32_t block, uint32_t count)
 {
     const DecodeArgs &A = V.d;
     const uint32_t total = A.numPackets * A.numChannels;
@@ -1182,19 +1163,10 @@ __device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, CoopTile &S, 
     }
     int32_t tp = o16[15 - T];  // out[j - T - 1]
 
-    // ---- 32-step blocks = one 128-byte line of the lane's row: the eight 16-byte loads of a block are issued back to back,
-    // so the line is fetched from L2 once (with two loads per 8 steps the line had left the L1 — 10 waves x 64 rows — before
-    // its next quarter was wanted: four L2 requests per line).  The residuals of block i + 1 are loaded while block i computes.
+    // ---- 32-step blocks (load32) ----
     const uint32_t nMax = wave_max_u32(n);
-    const uint32_t lane = threadIdx.x & 63;
-    S.rowOf[lane] = row;  // (a lane without a chain points at chain 0's row: in bounds, never used)
-    asm volatile("" ::: "memory");
-    // rows are frameSize long and the plane is padded by 256 bytes: the (unused) over-read of the last block, at most
-    // 31 samples past the longest row, stays inside; a lane also reads the rows of its wave's other lanes (coop_load) — this
-    // kernel works IN PLACE, but every lane of the wave writes block i back only after the loads of block i + 1 were issued,
-    // and nobody outside the wave touches these rows
-    CoopRegs tA, tB;
-    if (32 < nMax) coop_load(S, lane, 32, tA);
+    int32_t dA[32], dB[32];
+    if (32 < nMax) load32(row, 32, dA);
     if (16 < nMax) {
         // samples 16 .. 31 on their own, so that the 32-step blocks start on a line boundary (rows of the usual frame sizes
         // are 128-byte aligned)
@@ -1213,10 +1185,8 @@ __device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, CoopTile &S, 
         for (int q = 0; q < 4; q++)
             if (active && 16 + 4 * q < n) *(int4 *)(row + 16 + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
     }
-    auto step32 = [&](uint32_t jb, const CoopRegs &curT, CoopRegs &nxtT) {
-        int32_t cur[32];
-        coop_take(S, lane, curT, cur);
-        if (jb + 32 < nMax) coop_load(S, lane, jb + 32, nxtT);
+    auto step32 = [&](uint32_t jb, const int32_t (&cur)[32], int32_t (&nxt)[32]) {
+        if (jb + 32 < nMax) load32(row, jb + 32, nxt);
         int32_t o[32];
 #pragma unroll
         for (int s2 = 0; s2 < 32; s2++) o[s2] = lms_step_dec_wide<T>(a, w, tp, cur[s2], chanbits);
@@ -1225,8 +1195,8 @@ __device__ __forceinline__ void unpc_wide_body(const DecV1Args &V, CoopTile &S, 
             if (active && jb + 4 * q < n) *(int4 *)(row + jb + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
     };
     for (uint32_t jb = 32; jb < nMax; jb += 64) {
-        step32(jb, tA, tB);
-        if (jb + 32 < nMax) step32(jb + 32, tB, tA);
+        step32(jb, dA, dB);
+        if (jb + 32 < nMax) step32(jb + 32, dB, dA);
     }
 }
 
@@ -1277,7 +1247,7 @@ __device__ __forceinline__ int32_t lms_step_dec_any(int32_t (&a)[8], int32_t (&w
     return out;
 }
 
-__device__ __forceinline__ void unpc_any_body(const DecV1Args &V, CoopTile &S, uint32_t block, uint32_t count)
+__device__ __forceinline__ void unpc_any_body(const DecV1Args &V, uint32_t block, uint32_t count)
 {
     const DecodeArgs &A = V.d;
     if (block * 64u >= count) return;
@@ -1354,10 +1324,8 @@ __device__ __forceinline__ void unpc_any_body(const DecV1Args &V, CoopTile &S, u
         }
     }
     const uint32_t nMax = wave_max_u32(n);
-    S.rowOf[lane] = row;
-    asm volatile("" ::: "memory");
-    CoopRegs tA, tB;
-    if (32 < nMax) coop_load(S, lane, 32, tA);
+    int32_t dA[32], dB[32];
+    if (32 < nMax) load32(row, 32, dA);
     if (16 < nMax) {
         int32_t d[16], o[16];
 #pragma unroll
@@ -1374,10 +1342,8 @@ __device__ __forceinline__ void unpc_any_body(const DecV1Args &V, CoopTile &S, u
         for (int q = 0; q < 4; q++)
             if (active && 16 + 4 * q < n) *(int4 *)(row + 16 + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
     }
-    auto step32 = [&](uint32_t jb, const CoopRegs &curT, CoopRegs &nxtT) {
-        int32_t cur[32];
-        coop_take(S, lane, curT, cur);
-        if (jb + 32 < nMax) coop_load(S, lane, jb + 32, nxtT);
+    auto step32 = [&](uint32_t jb, const int32_t (&cur)[32], int32_t (&nxt)[32]) {
+        if (jb + 32 < nMax) load32(row, jb + 32, nxt);
         int32_t o[32];
 #pragma unroll
         for (int s2 = 0; s2 < 32; s2++) o[s2] = lms_step_dec_any(a, w, tp, cur[s2], chanbits, L);
@@ -1386,8 +1352,8 @@ __device__ __forceinline__ void unpc_any_body(const DecV1Args &V, CoopTile &S, u
             if (active && jb + 4 * q < n) *(int4 *)(row + jb + 4 * q) = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
     };
     for (uint32_t jb = 32; jb < nMax; jb += 64) {
-        step32(jb, tA, tB);
-        if (jb + 32 < nMax) step32(jb + 32, tB, tA);
+        step32(jb, dA, dB);
+        if (jb + 32 < nMax) step32(jb + 32, dB, dA);
     }
 }
 
@@ -1435,7 +1401,7 @@ __device__ __forceinline__ int32_t lms_step_dec_pair(int32_t (&a)[T], int32_t (&
 }
 
 template <int T, int DEPTH = 16>
-__device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, CoopTile &S, uint32_t block, uint32_t count)
+__device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, uint32_t block, uint32_t count)
 {
     const DecodeArgs &A = V.d;
     if (block * 32u >= count) return;
@@ -1602,10 +1568,8 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, CoopTile &S, 
     int32_t tp = T == 4 ? o16[11] : (is4 ? o16[11] : o16[7]);
 
     const uint32_t nMax = wave_max_u32(n);
-    S.rowOf[lane] = row;
-    asm volatile("" ::: "memory");
-    CoopRegs tA, tB;
-    if (32 < nMax) coop_load(S, lane, 32, tA);
+    int32_t dA[32], dB[32];
+    if (32 < nMax) load32(row, 32, dA);
     if (16 < nMax) {
         int32_t d[16], o[16];
 #pragma unroll
@@ -1620,18 +1584,16 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, CoopTile &S, 
         for (int s2 = 0; s2 < 16; s2++) o[s2] = lms_step_dec_pair<T>(a, w, tp, d[s2], chanbits, is4, act, wg);
         emit(o, std::integral_constant<int, 16>{}, 16);
     }
-    auto step32 = [&](uint32_t jb, const CoopRegs &curT, CoopRegs &nxtT) {
-        int32_t cur[32];
-        coop_take(S, lane, curT, cur);
-        if (jb + 32 < nMax) coop_load(S, lane, jb + 32, nxtT);
+    auto step32 = [&](uint32_t jb, const int32_t (&cur)[32], int32_t (&nxt)[32]) {
+        if (jb + 32 < nMax) load32(row, jb + 32, nxt);
         int32_t o[32];
 #pragma unroll
         for (int s2 = 0; s2 < 32; s2++) o[s2] = lms_step_dec_pair<T>(a, w, tp, cur[s2], chanbits, is4, act, wg);
         emit(o, std::integral_constant<int, 32>{}, jb);
     };
     for (uint32_t jb = 32; jb < nMax; jb += 64) {
-        step32(jb, tA, tB);
-        if (jb + 32 < nMax) step32(jb + 32, tB, tA);
+        step32(jb, dA, dB);
+        if (jb + 32 < nMax) step32(jb + 32, dB, dA);
     }
 }
 
@@ -1645,21 +1607,19 @@ __device__ __forceinline__ void unpc_pair_body(const DecV1Args &V, CoopTile &S, 
 template <int DEPTH>
 __global__ __launch_bounds__(64 * kEntWavesPerWg) void k_dec_unpc_wide(DecV1Args V)
 {
-    __shared__ CoopTile tiles[kEntWavesPerWg];
-    CoopTile &S = tiles[threadIdx.x >> 6];
     const uint32_t *cnt = dec_lists(V).cnt;
     const uint32_t c4 = cnt[0], c8 = cnt[1], pA = cnt[2], pB = cnt[3], cAny = cnt[6];
     const uint32_t nbB = (pB + 31u) / 32u, nb8 = (c8 + 63u) / 64u, nbA = (pA + 31u) / 32u, nb4 = (c4 + 63u) / 64u;
     uint32_t b = blockIdx.x * (uint32_t)kEntWavesPerWg + (threadIdx.x >> 6);
-    if (b < nbB) return unpc_pair_body<8, DEPTH>(V, S, b, pB);
+    if (b < nbB) return unpc_pair_body<8, DEPTH>(V, b, pB);
     b -= nbB;
-    if (b < nb8) return unpc_wide_body<8>(V, S, b, c8);
+    if (b < nb8) return unpc_wide_body<8>(V, b, c8);
     b -= nb8;
-    if (b < nbA) return unpc_pair_body<4, DEPTH>(V, S, b, pA);
+    if (b < nbA) return unpc_pair_body<4, DEPTH>(V, b, pA);
     b -= nbA;
-    if (b < nb4) return unpc_wide_body<4>(V, S, b, c4);
+    if (b < nb4) return unpc_wide_body<4>(V, b, c4);
     b -= nb4;
-    unpc_any_body(V, S, b, cAny);  // other encoders' chains (none in a stream of this library's or Apple's encoder)
+    unpc_any_body(V, b, cAny);  // other encoders' chains (none in a stream of this library's or Apple's encoder)
 }
 
 // ---- fused launch: the followers of an entropy wave are waves of ITS workgroup.  A workgroup = the entropy

@@ -349,8 +349,8 @@ def encode_roofline(fmt, B, total_bytes, stage_ms, thru_hint):
             "traffic_whole_step": traffic_step,
             "traffic_upper_bound": traffic_upper, "traffic_whole_step_upper_bound": traffic_step_upper,
             "traffic_how": "reads = FETCH_SIZE x the factor calibrated on the kernel's read shape (2.0 coalesced streams, 1.466 the "
-                           "predictor's staging, 1.0 one-lane-per-row loads; tools/fetch_calibrate.hip as MI355X_MICROARCH.md asks "
-                           "for access shapes other than wide streaming reads), writes = WRITE_SIZE; *_upper_bound = 2 x FETCH_SIZE "
+                           "predictor's staging, 1.43 the entropy decoder's word stream; tools/fetch_calibrate.hip as "
+                           "MI355X_MICROARCH.md asks for access shapes other than wide streaming reads), writes = WRITE_SIZE; *_upper_bound = 2 x FETCH_SIZE "
                            "+ WRITE_SIZE whatever the shape (what rounds 1-3 reported)",
             "kernel": dom, "kernel_symbol": sym, "longest_stage": longest,
             "kernel_ms": round(ms_dom, 4), "launches_per_step": n_dom,

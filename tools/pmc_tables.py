@@ -19,9 +19,11 @@ for this library's read shapes (profiles/r04/fetch_calibration.json, known bytes
     stream16      64 lanes x 16 B consecutive                                  2.000   (packer, k_dec_stage, un-mix, planes)
     rows192       predictor staging: 12 lanes cover 192 contiguous bytes of one packet row, rows 16 KB apart,
                   64 of every 192 bytes re-read one tile later                 1.466   (1.713 without the re-read)
-    lane_rows16   one lane = one row, 16-B loads                               0.444   (the counter is EXACT here: 64-B
-                  requests, and each line is fetched 2.25 times before the lane has used it up)
-so reads = FACTOR[kernel's dominant shape] * FETCH_SIZE * 1024 with factor 2.0 / 1.466 / 1.0 (READ_FACTOR below); every
+    lane_rows16   one lane = one row, ONE 16-B load per iteration                0.444   (the counter is exact here: 64-B
+                  requests, and each line is fetched 2.25 times before the lane has used it up) — no kernel of the library
+                  reads like this any more; the decoder's one-lane predictors issue a line's eight loads back to back
+so reads = FACTOR[kernel's dominant shape] * FETCH_SIZE * 1024 with factor 2.0 / 1.466 (staging) / 1.43 (the entropy decoder's
+word stream, from its known distinct bytes) (READ_FACTOR below); every
 table also carries the blanket 2 x figure rounds 1-3 reported (`_upper_bound`) and the uncorrected counter (`_counter_raw`).
 WRITE_SIZE is exact for 16-B stores (calibrated 1.000); scattered 4-byte stores are counted at 64 B per request (0.113).
 Every table is stored with the fingerprint of the kernel sources it was collected on (alac_amd.source_fingerprint(),
@@ -56,7 +58,11 @@ STAGE_OF = [
 READ_FACTOR = [
     ("k_search1_lane", 1.466), ("k_search2_lane", 1.466), ("k_class_final", 1.466), ("k_final_fused", 1.466),
     ("k_search1_fused", 1.466), ("k_lms_search", 1.466), ("k_lms_final", 1.466),
-    ("k_dec_entropy_wide", 1.0), ("k_dec_unpc_wide", 1.0), ("k_dec_fused_wg", 1.0), ("k_dec_unpc", 1.0),
+    # decoder: checked against KNOWN distinct bytes at 125 000 packets — k_dec_entropy_wide reads the 853 MB stream once
+    # (counter 598 MB: 1.43); k_dec_unpc_wide reads 3.6 GB of residual rows once (counter 1.84 GB: 1.95, i.e. whole-line
+    # requests: the default 2.0 applies — the one-lane-per-row shape of the calibration, one 16-byte load per iteration, is NOT
+    # what this kernel does: its eight loads of a line are issued back to back)
+    ("k_dec_entropy_wide", 1.43),
 ]
 
 
@@ -117,7 +123,7 @@ def main():
             fp = f.read().strip()
     note = {"_note": "bytes (resp. wave-instructions) per PASS = sum over every launch in the profiled run / passes; reads = "
                      "READ_FACTOR(kernel) * FETCH_SIZE KiB * 1024 with the factor calibrated on the kernel's dominant read shape "
-                     "(tools/fetch_calibrate.hip: 2.0 coalesced, 1.466 predictor staging, 1.0 one-lane-per-row), writes = "
+                     "(tools/fetch_calibrate.hip: 2.0 coalesced, 1.466 predictor staging; 1.43 the entropy decoder's word stream), writes = "
                      "WRITE_SIZE KiB * 1024; _upper_bound = the blanket 2 x FETCH_SIZE + WRITE_SIZE of rounds 1-3; tools/pmc_tables.py"}
     fpath, wpath = os.path.join(a.dir, "pmc_fetch_size.csv"), os.path.join(a.dir, "pmc_write_size.csv")
     if os.path.exists(fpath) and os.path.exists(wpath):
