@@ -38,15 +38,15 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; 12 keeps
-                                  // the 16-byte PCM loads of the staging aligned)
+constexpr int kHist = 12;         // samples kept in front of a tile (>= 9: in[j-9] is "top" for 8 taps; a multiple of 4:
+                                  // the checked staging works in groups of 4 samples)
 // Tile geometry by lanes per chain.  One lane per chain = 64 chains per wave: a 64-step tile would take 23 KB of LDS per
 // wave (6 waves per CU); 32 steps take 14.8 KB (10 per CU).  These mappings run where many waves share a SIMD (throughput
 // regime) or off the critical path (the 4-tap rows of the search), so the extra tile boundaries are cheap there.
 template <int LPC>
 struct Geo {
     static constexpr int TILE = LPC == 1 ? 32 : 64;   // predictor steps per LDS tile
-    static constexpr int ROWLEN = kHist + TILE + 4;   // staged samples per row (80 / 48)
+    static constexpr int ROWLEN = kHist + TILE;       // samples per row: the history in front of the tile + the tile (76 / 44)
     static constexpr int STRIDE = ROWLEN + 9;         // dwords per input row: + 9 cells of operand prefetch over-read /
                                                       // warm-up parking; odd (89 / 57)
 };
@@ -182,15 +182,14 @@ struct RowWait {
 template <int LPC>
 struct LmsShared {
     static constexpr int SLOTS = 64 / LPC;
-    int32_t xs[(SLOTS + 2) * Geo<LPC>::STRIDE];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
-                                          // the residuals as the steps pass (+ two dump rows: inert lanes, and the u / v
-                                          // of the surplus staging tasks when TASKS is not a multiple of 64)
+    int32_t xs[(SLOTS + 1) * Geo<LPC>::STRIDE];  // chain inputs (mixed / widened samples), one row per chain, overwritten by
+                                          // the residuals as the steps pass (+ a dump row for inert lanes)
     int32_t zero[kZeroCells];
     uint32_t pktIdx[SLOTS], pktN[SLOTS];  // per input row: packet and its valid samples
     int32_t rowMix[SLOTS];                // mixRes of the row's packet (this pass)
 };
 
-// Staging of x[j0 - kHist .. j0 + kTile + 4) of every chain of the wave, split in two so that the global
+// Staging of x[j0 - kHist .. j0 + kTile) of every chain of the wave, split in two so that the global
 // loads of tile t+1 are in flight while tile t computes:
 //   stage_load   16-byte PCM loads (4 sample-frames per lane task) into registers
 //   stage_store  stereo mix (codec/matrix_enc.cu:72-99 and the 20/24/32-bit forms) or mono widening, then LDS;
@@ -341,9 +340,15 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
     }
 }
 
-// ---- interior fast path of the staging (tile and its history fully inside every packet of the
-// wave): everything that does not change from tile to tile is computed once per pass, and a tile costs one
-// few vector loads plus the mix and the LDS writes per task — no bounds checks, no branches.
+// ---- interior fast path of the staging (the tile fully inside every packet of the wave): everything that does not change
+// from tile to tile is computed once per pass, and a tile costs a few vector loads plus the mix and the LDS writes per task —
+// no bounds checks, no branches.  Only the TILE new samples of a row are loaded: the kHist samples in front of them are the
+// last cells of the tile before, which the steps leave intact (residual j lands in cell j - j0, the youngest sample a step
+// still needs sits kHist - 9 cells further) — keep_history moves them to the front of the row.  Round 4: until then every
+// tile re-read its history from the PCM (48 samples staged per 32 steps): a third more requests than bytes, which reach the
+// fabric again because a tile's 3 000+ instructions lie between the two reads of a line, and a third more staging registers —
+// the ones k_search1_lane / k_search2_lane spilled.  With TILE * bytes-per-frame = 128 a 16-bit stereo row is one aligned
+// cache line per tile.
 // (Round 4 measured a COMPACT form of this plan for the 64-chains-per-wave kernels — a 32-bit offset from a wave-uniform base,
 // the LDS cell and the mixRes per task, 18 instead of 42 registers — because the compiler spills the 64-bit task addresses there
 // (256-register budget).  tools/scratch_sites.py shows why it changed nothing: the spilled values are reloaded in the per-PASS
@@ -351,11 +356,12 @@ __device__ __forceinline__ void stage_store(const StageRegs<CH, LPC> &R, LmsShar
 // either way.  Not kept.)
 template <int CH, int LPC>
 struct StagePlan {
-    static constexpr int ITERS = StageRegs<CH, LPC>::ITERS;
-    const uint8_t *pk[ITERS];  // address of the task's 4 sample-frames when the tile starts at j0 = kHist
+    static constexpr int TASKS = (64 / LPC / CH) * (Geo<LPC>::TILE / 4);  // (packet, 4-sample group of the tile) pairs
+    static constexpr int ITERS = TASKS / 64;
+    static_assert(TASKS % 64 == 0 && ITERS <= StageRegs<CH, LPC>::ITERS, "every lane has a task in every round");
+    const uint8_t *pk[ITERS];  // address of the task's 4 sample-frames when the tile starts at j0 = 0
     int xs[ITERS];             // LDS cell of the task's first u (v follows one row further)
     int32_t wl[ITERS], wr[ITERS], vsel[ITERS];  // u = (wl l + wr r) >> 2; v = vsel ? l - r : r
-    int32_t keep[ITERS];       // 0 for the tasks in front of sample 0 when the first tile is staged (HEAD), else -1
     bool usable;               // dword-aligned packets
 };
 
@@ -363,42 +369,50 @@ template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_plan(StagePlan<CH, LPC> &P, const LmsShared<LPC> &sh, const uint8_t *pcm,
                                            uint32_t frameBytes, int lane)
 {
-    constexpr int GROUPS = Geo<LPC>::ROWLEN / 4;
+    constexpr int GROUPS = Geo<LPC>::TILE / 4;
     constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);  // bytes per sample-frame = dwords per 4-frame task
     P.usable = task_vec_ok<DEPTH, CH>(frameBytes);
 #pragma unroll
     for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
         const int idx = it * 64 + lane;
         const int q = idx / GROUPS, grp = idx - q * GROUPS;
-        // 16 chains per wave make 160 tasks: the 32 surplus lanes of the third round load row 0's samples again and
-        // store into the dump rows (the fast paths carry no per-task predicate)
-        const bool real = idx < StageRegs<CH, LPC>::TASKS;
-        const int row = real ? q * CH : 0;
+        const int row = q * CH;
         P.pk[it] = pcm + (uint64_t)sh.pktIdx[row] * frameBytes + grp * (4 * BPF);
-        P.xs[it] = (real ? row : StageRegs<CH, LPC>::SLOTS) * Geo<LPC>::STRIDE + grp * 4;
+        P.xs[it] = row * Geo<LPC>::STRIDE + kHist + grp * 4;
         const int32_t r = CH == 2 ? sh.rowMix[row] : 0;
         P.wl[it] = r ? r : (1 << kMixBits);
         P.wr[it] = r ? (1 << kMixBits) - r : 0;
         P.vsel[it] = r ? -1 : 0;
-        P.keep[it] = grp < kHist / 4 ? 0 : -1;
     }
 }
 
-// HEAD: the tile that starts at sample 0 — the kHist samples in front of it are zeros, their tasks load nothing
-template <int DEPTH, int CH, int LPC, bool HEAD = false>
+// the TILE new samples of tile j0
+template <int DEPTH, int CH, int LPC>
 __device__ __forceinline__ void stage_load_fast(StageRegs<CH, LPC> &R, const StagePlan<CH, LPC> &P, int j0)
 {
     constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
-    const int64_t byteOff = (int64_t)(j0 - kHist) * BPF;
+    const int64_t byteOff = (int64_t)j0 * BPF;
 #pragma unroll
-    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) {
-        if constexpr (HEAD) {
+    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++) task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
+}
+
+// The history of the next tile: the last kHist samples of this one, cells TILE .. TILE + kHist - 1 of every row, move to cells
+// 0 .. kHist - 1 (HEAD: the tile that starts at sample 0 has zeros there).  Every lane moves 12 / LPC cells.
+template <int LPC, bool HEAD = false>
+__device__ __forceinline__ void keep_history(LmsShared<LPC> &sh, int lane)
+{
+    constexpr int SLOTS = 64 / LPC, N = kHist * SLOTS / 64;
+    static_assert(kHist * SLOTS % 64 == 0, "every lane moves the same number of cells");
+    int32_t v[N];
 #pragma unroll
-            for (int k = 0; k <= BPF; k++) R.v[it][k] = 0;
-            if (P.keep[it]) task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
-        } else {
-            task_load<DEPTH, CH>(P.pk[it] + byteOff, R.v[it]);
-        }
+    for (int it = 0; it < N; it++) {
+        const int idx = it * 64 + lane, row = idx % SLOTS, c = idx / SLOTS;
+        v[it] = HEAD ? 0 : sh.xs[row * Geo<LPC>::STRIDE + Geo<LPC>::TILE + c];
+    }
+#pragma unroll
+    for (int it = 0; it < N; it++) {
+        const int idx = it * 64 + lane, row = idx % SLOTS, c = idx / SLOTS;
+        sh.xs[row * Geo<LPC>::STRIDE + c] = v[it];
     }
 }
 
@@ -548,15 +562,17 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
     StageRegs<CH, LPC> R;
     StagePlan<CH, LPC> SP;
     stage_plan<DEPTH, CH, LPC>(SP, sh, A.S.pcm, frameBytes, lane);
-    // staged window [j - kHist, j - kHist + kRowLen) inside every packet of the wave -> fast staging of tile j
+    // tile [j, j + TILE) inside every packet of the wave -> fast staging of tile j (for j > 0 its history is in the row: the
+    // tile before was staged whole, by either path)
     const uint32_t nMinRows = wave_min_u32(J.active ? J.N : idleVal);
-    auto interior = [&](int j) { return SP.usable && j >= kHist && (uint32_t)(j - kHist + Geo<LPC>::ROWLEN) <= nMinRows; };
+    auto interior = [&](int j) { return SP.usable && (uint32_t)(j + Geo<LPC>::TILE) <= nMinRows; };
     if (runTo > 0) {
-        if (SP.usable && (uint32_t)(Geo<LPC>::ROWLEN - kHist) <= nMinRows) {  // first tile inside every packet: no bounds checks
+        if (interior(0)) {  // first tile inside every packet: no bounds checks
+            keep_history<LPC, true>(sh, lane);
             if (head && headMode == 2) {
                 stage_store_fast<DEPTH, CH, LPC>(*head, SP, sh);
             } else {
-                stage_load_fast<DEPTH, CH, LPC, true>(R, SP, 0);
+                stage_load_fast<DEPTH, CH, LPC>(R, SP, 0);
                 if (head && headMode == 1) *head = R;
                 stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
             }
@@ -622,8 +638,13 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
             if (flag && ((((j0 / Geo<LPC>::TILE) & A.pubMask & 0xff) == (A.pubMask & 0xff)) || !more)) publish_rows(flag, flagBase + (uint32_t)min(j0 + Geo<LPC>::TILE, (int)runTo), lane, (A.pubMask >> 31) != 0, A.ho.lose);
         }
         lds_order();
-        if (fastNext) stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
-        else if (more) stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + Geo<LPC>::TILE, lane);
+        if (fastNext) {
+            keep_history<LPC>(sh, lane);
+            lds_order();
+            stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
+        } else if (more) {
+            stage_store<DEPTH, CH, LPC>(R, sh, A.S.pcm, frameBytes, j0 + Geo<LPC>::TILE, lane);
+        }
     }
 }
 
