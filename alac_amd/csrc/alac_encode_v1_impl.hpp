@@ -573,7 +573,15 @@ __device__ __forceinline__ void lms_pass(LmsShared<LPC> &sh, const V1Args &A, co
                 stage_store_fast<DEPTH, CH, LPC>(*head, SP, sh);
             } else {
                 stage_load_fast<DEPTH, CH, LPC>(R, SP, 0);
-                if (head && headMode == 1) *head = R;
+                if (head && headMode == 1) {
+                    // the dwords the fast path loaded, one by one: a copy of the whole struct (its unused cells included)
+                    // kept *head in scratch memory for the 20- / 24- / 32-bit instances
+                    constexpr int BPF = CH * (int)bytes_per_sample(DEPTH);
+#pragma unroll
+                    for (int it = 0; it < StagePlan<CH, LPC>::ITERS; it++)
+#pragma unroll
+                        for (int k = 0; k <= BPF; k++) head->v[it][k] = R.v[it][k];
+                }
                 stage_store_fast<DEPTH, CH, LPC>(R, SP, sh);
             }
         } else {

@@ -348,8 +348,8 @@ def encode_roofline(fmt, B, total_bytes, stage_ms, thru_hint):
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tnote,
             "traffic_whole_step": traffic_step,
             "traffic_upper_bound": traffic_upper, "traffic_whole_step_upper_bound": traffic_step_upper,
-            "traffic_how": "reads = FETCH_SIZE x the factor calibrated on the kernel's read shape (2.0 coalesced streams, 1.466 the "
-                           "predictor's staging, 1.43 the entropy decoder's word stream; tools/fetch_calibrate.hip as "
+            "traffic_how": "reads = FETCH_SIZE x the factor calibrated on the kernel's read shape (2.0 coalesced streams and the "
+                           "16-bit predictor staging, 1.707 the 20- / 24-bit staging, 1.43 the entropy decoder's word stream; tools/fetch_calibrate.hip as "
                            "MI355X_MICROARCH.md asks for access shapes other than wide streaming reads), writes = WRITE_SIZE; *_upper_bound = 2 x FETCH_SIZE "
                            "+ WRITE_SIZE whatever the shape (what rounds 1-3 reported)",
             "kernel": dom, "kernel_symbol": sym, "longest_stage": longest,

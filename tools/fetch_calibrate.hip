@@ -7,6 +7,9 @@
 //   k_rows192<OV>     the predictor staging (stage_load_fast, LPC = 1): a wave's 64 lanes read 16 B each, 12 consecutive lanes
 //                     cover 192 contiguous bytes of ONE packet row, rows 16 KB apart (packet stride); OV = 1 re-reads 64 of every
 //                     192 bytes one tile later (the history in front of a tile: ROWLEN 48 samples per TILE of 32)
+//   k_rows128         the predictor staging since round 4 kept the history of a tile in LDS: 8 consecutive lanes cover the 128 new
+//                     bytes of ONE packet row (16-bit stereo: one aligned line per row and tile), rows 16 KB apart, no re-reads;
+//                     24-bit stereo stages 192 bytes per row and tile without overlap = k_rows192<0>
 //   k_lane_rows16     one lane = one row: every lane streams through its own row with 16-B loads (entropy decoder's word
 //                     stream, one-lane predictor of the decoder: 64 lanes, 64 different lines per instruction)
 //   k_lane_rows4      the same with 4-byte loads (coder row loads of the planes are 256-B rows: covered by k_stream16)
@@ -54,6 +57,23 @@ __global__ void k_rows192(const uint8_t *in, uint32_t rows, uint32_t rowBytes, u
 #pragma unroll
         for (int it = 0; it < 6; it++) {
             const uint32_t idx = it * 64 + lane, q = idx / 12, g = idx % 12;
+            const U4 v = *(const U4 *)(in + (uint64_t)(row0 + q) * rowBytes + off + g * 16);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+__global__ void k_rows128(const uint8_t *in, uint32_t rows, uint32_t rowBytes, uint32_t *sink)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const uint32_t row0 = wave * 32;
+    if (row0 >= rows) return;
+    uint32_t acc = 0;
+    for (uint32_t off = 0; off + 128 <= rowBytes; off += 128) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const uint32_t idx = it * 64 + lane, q = idx / 8, g = idx % 8;
             const U4 v = *(const U4 *)(in + (uint64_t)(row0 + q) * rowBytes + off + g * 16);
             acc ^= v.x ^ v.y ^ v.z ^ v.w;
         }
@@ -119,6 +139,7 @@ int main()
     printf("EXPECT k_rows192<0> read %llu\n", (unsigned long long)((uint64_t)rows * tilesNo * 192));
     printf("EXPECT k_rows192<1> read %llu requested %llu\n", (unsigned long long)((uint64_t)rows * (tilesOv * 128 + 64)),
            (unsigned long long)((uint64_t)rows * tilesOv * 192));
+    printf("EXPECT k_rows128 read %llu\n", (unsigned long long)total);
     printf("EXPECT k_lane_rows<16> read %llu\n", (unsigned long long)total);
     printf("EXPECT k_lane_rows<4> read %llu\n", (unsigned long long)total);
     printf("EXPECT k_store16 write %llu\n", (unsigned long long)total);
@@ -128,6 +149,7 @@ int main()
         hipLaunchKernelGGL(k_stream16, dim3(8192), dim3(256), 0, 0, (const U4 *)buf, total / 16, sink);
         hipLaunchKernelGGL(k_rows192<0>, dim3(rows / 32 / 4), dim3(256), 0, 0, buf, rows, rowBytes, sink);
         hipLaunchKernelGGL(k_rows192<1>, dim3(rows / 32 / 4), dim3(256), 0, 0, buf, rows, rowBytes, sink);
+        hipLaunchKernelGGL(k_rows128, dim3(rows / 32 / 4), dim3(256), 0, 0, buf, rows, rowBytes, sink);
         hipLaunchKernelGGL(k_lane_rows<16>, dim3(rows / 256), dim3(256), 0, 0, buf, rows, rowBytes, sink);
         hipLaunchKernelGGL(k_lane_rows<4>, dim3(rows / 256), dim3(256), 0, 0, buf, rows, rowBytes, sink);
         hipLaunchKernelGGL(k_store16, dim3(8192), dim3(256), 0, 0, (U4 *)buf, total / 16);

@@ -17,13 +17,17 @@ FETCH_SIZE tallies a 128-B request as 64 B, so a WIDE COALESCED streaming read i
 widths are uncalibrated: calibrate on a known byte count in your own access pattern".  tools/fetch_calibrate.hip does that
 for this library's read shapes (profiles/r04/fetch_calibration.json, known bytes / counter bytes):
     stream16      64 lanes x 16 B consecutive                                  2.000   (packer, k_dec_stage, un-mix, planes)
-    rows192       predictor staging: 12 lanes cover 192 contiguous bytes of one packet row, rows 16 KB apart,
-                  64 of every 192 bytes re-read one tile later                 1.466   (1.713 without the re-read)
+    rows128       predictor staging, 16-bit stereo: 8 lanes cover the 128 new bytes of one packet row per tile (one aligned
+                  line), rows 16 KB apart, nothing re-read                      2.000
+    rows192<0>    the same for 20- / 24-bit stereo: 12 lanes, 192 bytes         1.707
+                  (until the staging kept a tile's history in LDS it re-read 64 of every 192 bytes one tile later: 1.466 on
+                  the calibration kernel, whose re-read follows at once and hits the L2 — in the real kernels a tile's
+                  3 000+ instructions lay between and the re-read went to the fabric again)
     lane_rows16   one lane = one row, ONE 16-B load per iteration                0.444   (the counter is exact here: 64-B
                   requests, and each line is fetched 2.25 times before the lane has used it up) — no kernel of the library
                   reads like this any more; the decoder's one-lane predictors issue a line's eight loads back to back
-so reads = FACTOR[kernel's dominant shape] * FETCH_SIZE * 1024 with factor 2.0 / 1.466 (staging) / 1.43 (the entropy decoder's
-word stream, from its known distinct bytes) (READ_FACTOR below); every
+so reads = FACTOR[kernel's dominant shape] * FETCH_SIZE * 1024 with factor 2.0 / 1.707 (20- / 24-bit staging) / 1.43 (the entropy
+decoder's word stream, from its known distinct bytes) (read_factor below); every
 table also carries the blanket 2 x figure rounds 1-3 reported (`_upper_bound`) and the uncorrected counter (`_counter_raw`).
 WRITE_SIZE is exact for 16-B stores (calibrated 1.000); scattered 4-byte stores are counted at 64 B per request (0.113).
 Every table is stored with the fingerprint of the kernel sources it was collected on (alac_amd.source_fingerprint(),
@@ -55,9 +59,8 @@ STAGE_OF = [
 
 
 # dominant READ shape of a kernel -> factor on FETCH_SIZE (module docstring); default 2.0 (coalesced)
+STAGING = ("k_search1_lane", "k_search2_lane", "k_class_final", "k_final_fused", "k_search1_fused", "k_lms_search", "k_lms_final")
 READ_FACTOR = [
-    ("k_search1_lane", 1.466), ("k_search2_lane", 1.466), ("k_class_final", 1.466), ("k_final_fused", 1.466),
-    ("k_search1_fused", 1.466), ("k_lms_search", 1.466), ("k_lms_final", 1.466),
     # decoder: checked against KNOWN distinct bytes at 125 000 packets — k_dec_entropy_wide reads the 853 MB stream once
     # (counter 598 MB: 1.43); k_dec_unpc_wide reads 3.6 GB of residual rows once (counter 1.84 GB: 1.95, i.e. whole-line
     # requests: the default 2.0 applies — the one-lane-per-row shape of the calibration, one 16-byte load per iteration, is NOT
@@ -67,6 +70,9 @@ READ_FACTOR = [
 
 
 def read_factor(k):
+    if any(sub in k for sub in STAGING):
+        m = re.search(r"<(\d+)", k)
+        return 1.707 if m and m.group(1) in ("20", "24") else 2.0  # rows192<0> / rows128 (and 32-bit: two whole lines)
     for sub, f in READ_FACTOR:
         if sub in k:
             return f
@@ -123,7 +129,7 @@ def main():
             fp = f.read().strip()
     note = {"_note": "bytes (resp. wave-instructions) per PASS = sum over every launch in the profiled run / passes; reads = "
                      "READ_FACTOR(kernel) * FETCH_SIZE KiB * 1024 with the factor calibrated on the kernel's dominant read shape "
-                     "(tools/fetch_calibrate.hip: 2.0 coalesced, 1.466 predictor staging; 1.43 the entropy decoder's word stream), writes = "
+                     "(tools/fetch_calibrate.hip: 2.0 coalesced and the 16-bit predictor staging, 1.707 the 20- / 24-bit staging; 1.43 the entropy decoder's word stream), writes = "
                      "WRITE_SIZE KiB * 1024; _upper_bound = the blanket 2 x FETCH_SIZE + WRITE_SIZE of rounds 1-3; tools/pmc_tables.py"}
     fpath, wpath = os.path.join(a.dir, "pmc_fetch_size.csv"), os.path.join(a.dir, "pmc_write_size.csv")
     if os.path.exists(fpath) and os.path.exists(wpath):

@@ -18,10 +18,12 @@ def main():
     res = {re.sub(r"\(.*", "", k["kernel"]): k for k in json.load(open(os.path.join(ROOT, "profiles", "r04", "kernel_resources.json")))["table"]}
     print("# HBM-side traffic per kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) with scratch and spill figures\n")
     print("Reads are priced at FETCH_SIZE x the factor calibrated on the kernel's dominant read shape (tools/fetch_calibrate.hip,")
-    print("profiles/r04/fetch_calibration.txt): 2.0 coalesced streams, 1.466 the predictor's PCM staging, 1.43 the entropy decoder's word stream;")
+    print("profiles/r04/fetch_calibration.txt): 2.0 coalesced streams and the 16-bit predictor staging (one aligned line per row and tile), 1.707 the 24-bit staging, 1.43 the entropy decoder's word stream;")
     print("`upper` is the blanket 2 x FETCH_SIZE + WRITE_SIZE of rounds 1-3.  Scratch = `.private_segment_fixed_size` per lane, spills =")
     print("`.vgpr_spill_count` / `.sgpr_spill_count` (tools/kernel_table.py); where a kernel touches scratch: tools/scratch_sites.py")
-    print("(k_search1_lane<16>, k_search2_lane<16, 2>: per-pass set-up only, no scratch access inside a tile loop).\n")
+    print("(k_search1_lane<16>, k_search2_lane<16, 2>: per-pass set-up only, no scratch access inside a tile loop).")
+    print("Collected after the predictor staging stopped re-reading a tile's history from the PCM (DESIGN.md section 4.0); the tables before that")
+    print("change are in git history (commit 3874e34: 125 000-packet encode step 11.18 GB calibrated / 13.95 GB upper).\n")
     for key in sys.argv[1:]:
         t = traffic[key]
         per = t.get("_per_kernel", {})
