@@ -8,6 +8,7 @@
 //
 // Reference: ALACDecoder::Decode codec/ALACDecoder.cu:571-1002, fillWriteBuffer :497-563,
 // dyn_decomp codec/ag_dec.c:272-362, unpc_block codec/dp_dec.c:55-381.
+#include <algorithm>
 #include <cstdlib>
 #include "alac_dev.hpp"
 #include "alac_kernels.hpp"
@@ -299,8 +300,14 @@ __global__ __launch_bounds__(256) void k_decode_unmix(DecodeArgs A)
     if (A.gate && *A.gate == 0) return;
     __shared__ int32_t tu[64][65];
     __shared__ int32_t tv[CH == 2 ? 64 : 1][65];
-    const uint32_t tileP = blockIdx.x * 64u, tileJ = blockIdx.y * 64u;
     const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    // tile = 64 packets x 64 samples; the plain launch has one workgroup per tile (2-D grid), the gated one (the lane decoder
+    // behind the fast pipeline, nothing to do unless some packet carried another element sequence) a small 1-D grid that walks
+    // the tiles: 500 000 workgroups that read the gate and left cost 28 us of every 125 000-packet decode
+    const uint32_t nPx = (A.numPackets + 63) / 64;
+    const uint64_t tiles = (uint64_t)nPx * ((A.frameSize + 63) / 64);
+    for (uint64_t tile = blockIdx.x + (uint64_t)gridDim.x * blockIdx.y; tile < tiles; tile += (uint64_t)gridDim.x * gridDim.y) {
+    const uint32_t tileP = (uint32_t)(tile % nPx) * 64u, tileJ = (uint32_t)(tile / nPx) * 64u;
 
     // load: consecutive lanes = consecutive packets (the residual layout's fast axis)
     for (uint32_t i = 0; i < 16; i++) {
@@ -348,6 +355,8 @@ __global__ __launch_bounds__(256) void k_decode_unmix(DecodeArgs A)
         store_sample<DEPTH>(op, l);
         if constexpr (CH == 2) store_sample<DEPTH>(op + BPS, r);
     }
+    __syncthreads();
+    }
 }
 
 // > 2 channels: the same tile walk once per output channel c; a packet's element that STARTS at c is un-mixed and
@@ -359,8 +368,11 @@ __global__ __launch_bounds__(256) void k_decode_unmix_mc(DecodeArgs A)
     if (A.gate && *A.gate == 0) return;
     __shared__ int32_t tu[64][65];
     __shared__ int32_t tv[64][65];
-    const uint32_t tileP = blockIdx.x * 64u, tileJ = blockIdx.y * 64u;
     const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const uint32_t nPx = (A.numPackets + 63) / 64;
+    const uint64_t tiles = (uint64_t)nPx * ((A.frameSize + 63) / 64);
+    for (uint64_t tile = blockIdx.x + (uint64_t)gridDim.x * blockIdx.y; tile < tiles; tile += (uint64_t)gridDim.x * gridDim.y) {
+    const uint32_t tileP = (uint32_t)(tile % nPx) * 64u, tileJ = (uint32_t)(tile / nPx) * 64u;
     constexpr uint32_t BPS = bytes_per_sample(DEPTH);
     const uint32_t nch = A.numChannels;
     for (uint32_t c = 0; c < nch; c++) {
@@ -410,12 +422,14 @@ __global__ __launch_bounds__(256) void k_decode_unmix_mc(DecodeArgs A)
         }
         __syncthreads();
     }
+    }
 }
 
 template <int DEPTH>
 static void launch_unmix_depth(const DecodeArgs &da, hipStream_t st)
 {
     dim3 grid((da.numPackets + 63) / 64, (da.frameSize + 63) / 64);
+    if (da.gate) grid = dim3((uint32_t)std::min<uint64_t>((uint64_t)grid.x * grid.y, 2048), 1);  // (see k_decode_unmix)
     // two channels may arrive as one CPE or as two SCE / LFE elements (codec/ALACDecoder.cu:622-756): the per-element
     // kernel follows the records, k_decode_unmix<., 2> would take the packet for one pair
     if (da.numChannels >= 2)

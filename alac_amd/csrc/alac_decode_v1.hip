@@ -34,6 +34,8 @@ namespace alacdev {
 constexpr uint32_t kFastChanBits = 23;  // widest sample the __mul24 predictor bodies take (see k_dec_header)
 constexpr int kDecRound = 16;    // symbols decoded between two restagings of the LDS ring
 constexpr int kWinWords = 16;    // words staged per lane per round (64 bytes)
+constexpr int kHdrWinWords = 17;  // k_dec_header: words of a packet's head kept in LDS per lane (64 bytes at any byte phase)
+constexpr int kHdrWinStride = 17; // odd: conflict-free columns
 constexpr int kWinStride = 33;   // LDS words per lane: a circular ring of 32 (+1: odd stride, conflict-free columns)
 
 // ---- k_dec_stage ---------------------------------------------------------------------------------
@@ -238,6 +240,37 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     DecRec *rec = A.recs + (live ? p : 0);
 
     uint64_t hpos = (live && V.elemBit) ? V.elemBit[p] : 0;
+    // The first 64 bytes of every packet (a compressed stereo element's header with two 8-tap coefficient sets is 45) as
+    // seventeen MSB-first words in LDS, bytes behind the packet's end zeroed as the byte reader reads them: a field is then two
+    // LDS words and a funnel shift instead of five byte loads, each a round trip of its own for 64 lanes in 64 different lines
+    // (the launch took 0.114 ms of the 5.1 ms decode pass at 125 000 packets for 3 M wave-instructions).  Fields outside the
+    // window, packets within 80 bytes of the stream's end and streams that are not dword aligned use the byte reader.
+    __shared__ uint32_t win[64 * kHdrWinStride];
+    const uint64_t totalBytes = A.offsets[A.numPackets];
+    const bool useWin = live && ((uintptr_t)A.stream & 3) == 0 && (off & ~3ull) + 4 * kHdrWinWords <= totalBytes;
+    const uint32_t phase = (uint32_t)(off & 3) * 8;  // bit of the packet's first byte inside window word 0
+    if (useWin) {
+        const uint32_t *sw = (const uint32_t *)(A.stream + (off & ~3ull));
+        const int64_t endRel = (int64_t)nbytes + (int64_t)(off & 3);  // first byte (window-relative) behind the packet
+#pragma unroll
+        for (int i = 0; i < kHdrWinWords; i++) {
+            uint32_t w = __builtin_bswap32(sw[i]);
+            const int64_t keep = endRel - 4 * i;  // bytes of this word that belong to the packet
+            if (keep <= 0) w = 0;
+            else if (keep < 4) w &= 0xffffffffu << (8 * (4 - (int)keep));
+            win[lane * kHdrWinStride + i] = w;
+        }
+    }
+    auto rd = [&](uint32_t n) -> uint32_t {
+        const uint64_t bit = hpos + phase;
+        if (useWin && bit + 32 <= 32ull * (kHdrWinWords - 1)) {
+            const uint32_t wi = (uint32_t)(bit >> 5), sh = (uint32_t)(bit & 31);
+            const uint64_t two = ((uint64_t)win[lane * kHdrWinStride + wi] << 32) | win[lane * kHdrWinStride + wi + 1];
+            hpos += n;
+            return n ? (uint32_t)((two << sh) >> 32) >> (32 - n) : 0u;
+        }
+        return read_bits(base, nbytes, hpos, n);
+    };
     uint32_t numSamples = A.frameSize, ech = 0, shb = 0, chanBits = 0, esc = 0;
     int32_t status = (live && V.round > 0) ? A.statusOut[p] : 0;  // a packet that failed in an earlier round stays failed
     uint32_t pbU = A.pb, pbV = A.pb;
@@ -258,7 +291,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                 status = -50;
                 break;
             }
-            const uint32_t tag = read_bits(base, nbytes, hpos, 3);
+            const uint32_t tag = rd(3);
             switch (tag) {
             case 0:    // ID_SCE
             case 3:    // ID_LFE
@@ -268,12 +301,12 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                     status = -4;
                     break;
                 }
-                (void)read_bits(base, nbytes, hpos, 4);
-                if (read_bits(base, nbytes, hpos, 12) != 0) {  // :633 / :768
+                (void)rd(4);
+                if (rd(12) != 0) {  // :633 / :768
                     status = -50;
                     break;
                 }
-                const uint32_t hb = read_bits(base, nbytes, hpos, 4);
+                const uint32_t hb = rd(4);
                 const uint32_t partial = hb >> 3;
                 shb = (hb >> 1) & 3;
                 esc = hb & 1;
@@ -282,20 +315,20 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                     break;
                 }
                 chanBits = A.bitDepth - shb * 8 + (ech == 2 ? 1 : 0);
-                if (partial) numSamples = read_bits(base, nbytes, hpos, 32);
+                if (partial) numSamples = rd(32);
                 if (numSamples > A.frameSize) {
                     status = -50;
                     break;
                 }
                 R.elementChannels = ech;
                 if (!esc) {
-                    R.mixBits = (int32_t)read_bits(base, nbytes, hpos, 8);
-                    R.mixRes = (int8_t)read_bits(base, nbytes, hpos, 8);
+                    R.mixBits = (int32_t)rd(8);
+                    R.mixRes = (int8_t)rd(8);
                     for (uint32_t c = 0; c < ech; c++) {
-                        uint32_t b = read_bits(base, nbytes, hpos, 8);
+                        uint32_t b = rd(8);
                         rec->c[c].mode = (uint16_t)(b >> 4);
                         rec->c[c].denShift = (uint16_t)(b & 0xf);
-                        b = read_bits(base, nbytes, hpos, 8);
+                        b = rd(8);
                         rec->c[c].pbFactor = (uint16_t)(b >> 5);
                         rec->c[c].num = (uint16_t)(b & 0x1f);
                         okc[c] = rec->c[c].mode == 0 && rec->c[c].denShift == kDenShift && ((b & 0x1f) == 4 || (b & 0x1f) == 8);
@@ -304,7 +337,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                         if (c == 0) pbU = (A.pb * (b >> 5)) / 4;  // :825
                         else pbV = (A.pb * (b >> 5)) / 4;        // :841
                         for (uint32_t i = 0; i < (b & 0x1f); i++)
-                            rec->c[c].coefs[i] = (int16_t)read_bits(base, nbytes, hpos, 16);
+                            rec->c[c].coefs[i] = (int16_t)rd(16);
                     }
                     R.shiftPos = hpos;
                     if (shb) hpos += (uint64_t)shb * 8 * ech * numSamples;
@@ -323,18 +356,18 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
                 status = -50;
                 break;
             case 4: {  // ID_DSE :1033-1059
-                (void)read_bits(base, nbytes, hpos, 4);
-                const uint32_t align = read_bits(base, nbytes, hpos, 1);
-                uint32_t count = read_bits(base, nbytes, hpos, 8);
-                if (count == 255) count += read_bits(base, nbytes, hpos, 8);
+                (void)rd(4);
+                const uint32_t align = rd(1);
+                uint32_t count = rd(8);
+                if (count == 255) count += rd(8);
                 if (align && (hpos & 7)) hpos += 8 - (hpos & 7);
                 hpos += (uint64_t)count * 8;
                 if ((hpos + 7) / 8 > nbytes) status = -50;
                 break;
             }
             case 6: {  // ID_FIL :1012-1027
-                int32_t count = (int32_t)read_bits(base, nbytes, hpos, 4);
-                if (count == 15) count += (int32_t)read_bits(base, nbytes, hpos, 8) - 1;
+                int32_t count = (int32_t)rd(4);
+                if (count == 15) count += (int32_t)rd(8) - 1;
                 hpos += (uint64_t)count * 8;
                 if ((hpos + 7) / 8 > nbytes) status = -50;
                 break;
@@ -438,7 +471,39 @@ __device__ __forceinline__ void raw_body(const DecV1Args &V, uint32_t p, uint32_
     // chain of dependent round trips per wave, not by bytes (an iteration per frame took 1.24 ms for the 15 600 escape
     // packets of the 125 000-packet benchmark)
     constexpr uint32_t U = 4;
-    for (uint32_t j0 = first; j0 < n; j0 += U * step) {
+    uint32_t done = 0;  // frames [0, done) are written by the group path below
+    if (direct && ech == 2 && w == 16) {
+        // The benchmark's escape packets (one in eight): frame j IS the 32 bits from bit bitBase + 32 j on — L then R, MSB first —
+        // so four frames are five consecutive words at one bit phase: a 16-byte load and a dword, four funnel shifts, four
+        // half-word swaps (the PCM word is L | R << 16), one 16-byte store.  The per-field code below spent ~100 instructions
+        // per frame on them (k_dec_raw 0.20 ms of the 5.1 ms decode pass at 125 000 packets, 87 M wave-instructions).
+        typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t s = (uint32_t)(bitBase & 31);
+        const uint64_t a0 = wbase + (bitBase >> 5);
+        // groups whose five words all come from the stream itself (DIRECT: in front of the tail copy; staged: inside the stage)
+        const uint64_t wordEnd = DIRECT ? tailStart : V.capWords - 2;
+        const uint32_t groups = n / 4;
+        uint32_t safe = 0;
+        if (a0 + 5 <= wordEnd) safe = (uint32_t)min((uint64_t)groups, (wordEnd - a0 - 5) / 4 + 1);
+        const uint32_t *src = DIRECT ? V.raw : V.words;
+        for (uint32_t g = first; g < safe; g += step) {
+            const U4 q = *(const U4 *)(src + a0 + 4 * (uint64_t)g);
+            const uint32_t e = src[a0 + 4 * (uint64_t)g + 4];
+            uint32_t x[5] = {q.x, q.y, q.z, q.w, e};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 5; k++) x[k] = DIRECT ? __builtin_bswap32(x[k]) : x[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t v = (uint32_t)(((((uint64_t)x[k] << 32) | x[k + 1]) << s) >> 32);
+                o[k] = (v >> 16) | (v << 16);
+            }
+            const U4 t4 = {o[0], o[1], o[2], o[3]};
+            *(U4 *)(pcm + 4 * (uint64_t)g) = t4;
+        }
+        done = safe * 4;
+    }
+    for (uint32_t j0 = done + first; j0 < n; j0 += U * step) {
         uint32_t hi[U][2], lo[U][2], shs[U][2];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
