@@ -93,7 +93,10 @@ void put_chan(Bytes &o, uint32_t tag)
     put_zeros(o, 8);
 }
 
-uint32_t bytes_per_sample(uint32_t bits) { return bits >> 3; }  // the reference's (mBitsPerChannel >> 3), main.cu:389
+// The reference sizes a sample as (mBitsPerChannel >> 3), main.cu:389 — 2 bytes for 20-bit material, which its own encoder
+// reads as 3-byte containers (mix20, copy20ToPredictor): it never handled a 20-bit file.  Here a 20-bit sample takes the 3-byte
+// container the codec reads (20 bits left-justified in 24, as WAVE and CAF store them); 16 / 24 / 32 bits are the reference's.
+uint32_t bytes_per_sample(uint32_t bits) { return (bits + 7) >> 3; }
 
 // Walk CAF chunks from offset 8 the way the reference's scanners do (12-byte header, size = low 32 bits of the
 // big-endian int64, no bounds other than end of file): position of the first chunk of type `want`, or npos.
@@ -352,7 +355,7 @@ Bytes build_wave(double sampleRate, uint32_t channels, uint32_t bits, const uint
     // main.cu:803-852 + the two size patches at :766-772
     Bytes o;
     o.reserve((size_t)pcmBytes + 44);
-    const uint32_t bytesPerFrame = channels * (bits >> 3);
+    const uint32_t bytesPerFrame = channels * bytes_per_sample(bits);
     const uint32_t rate = (uint32_t)sampleRate;
     put_tag(o, "RIFF");
     put_le32(o, (uint32_t)(pcmBytes + 4 + 8 + 24));
@@ -798,7 +801,7 @@ Bytes build_pcm_caf(double sampleRate, uint32_t channels, uint32_t bits, const u
     // main.cu:675-693 with SetOutputFormat's decode branch (:303-331) and WriteCAFFdescChunk's lpcm flags (:73-83)
     Bytes o;
     o.reserve((size_t)pcmBytes + 80);
-    const uint32_t bytesPerFrame = channels * (bits >> 3);
+    const uint32_t bytesPerFrame = channels * bytes_per_sample(bits);
     put_caf_file_header(o);
     put_desc(o, sampleRate, 0x6c70636du, 2 /* little endian */, bytesPerFrame, 1, channels, bits);
     if (channels > 2) put_chan(o, kLayoutTags[(channels - 1) & 7]);

@@ -85,7 +85,7 @@ AudioFormatDescription alac_format(const InputInfo &in)
 bool encode_group(std::vector<Job *> &jobs, uint32_t segmentPackets, int device)
 {
     const InputInfo &first = jobs[0]->info;
-    const uint32_t bps = first.bitsPerChannel >> 3, ch = first.channels;
+    const uint32_t bps = (first.bitsPerChannel + 7) >> 3, ch = first.channels;  // 20 bits: 3-byte containers (container.cpp)
     const uint32_t bytesPerFrame = bps * ch, frame = kALACDefaultFramesPerPacket;
     const uint64_t packetBytes = (uint64_t)bytesPerFrame * frame;
 
@@ -178,16 +178,15 @@ bool decode_group(std::vector<Job *> &jobs, const std::vector<alacfile::AlacCafC
         return false;
     }
     const uint32_t ch = dec.mConfig.numChannels, bits = dec.mConfig.bitDepth, frame = dec.mConfig.frameLength;
-    // The library writes 3 bytes per 20-bit sample; this tool (like the reference, main.cu:389) sizes PCM as bits / 8.
-    // The 'desc' flag was checked by the caller, but the COOKIE decides what the decoder writes: refuse a cookie
-    // whose depth this tool cannot size (20) or that contradicts the file's description.
+    // The 'desc' flag was checked by the caller, but the COOKIE decides what the decoder writes: refuse a cookie whose depth
+    // contradicts the file's description.  20 bits: 3-byte samples, left-justified, as the library writes them.
     for (size_t j = 0; j < jobs.size(); j++) {
-        if (bits == 20 || !(bits == 16 || bits == 24 || bits == 32) || source_bits(jobs[j]->info.alacSourceFlag) != bits) {
+        if (!(bits == 16 || bits == 20 || bits == 24 || bits == 32) || source_bits(jobs[j]->info.alacSourceFlag) != bits) {
             fprintf(stderr, " Magic cookie bit depth %u does not match the file description: \"%s\"\n", bits, jobs[j]->in.c_str());
             return false;
         }
     }
-    const uint32_t bytesPerFrame = ch * (bits >> 3);
+    const uint32_t bytesPerFrame = ch * ((bits + 7) >> 3);
     std::vector<uint32_t> sizes, firstPacket;
     Bytes stream;
     for (size_t j = 0; j < jobs.size(); j++) {
@@ -285,13 +284,7 @@ int main(int argc, char *argv[])
         }
         if (!J.info.isAlac) {
             const uint32_t b = J.info.bitsPerChannel;
-            if (b == 20) {
-                // the reference sizes 20-bit packets with (20 >> 3) = 2 bytes per sample (main.cu:389) while its
-                // encoder reads 3: it never handled 20-bit files; refuse instead of inventing behaviour
-                fprintf(stderr, " 20-bit PCM files are not supported by the convert utility: \"%s\"\n", J.in.c_str());
-                return 1;
-            }
-            if ((b != 16 && b != 24 && b != 32) || J.info.channels < 1 || J.info.channels > 8) {  // kALACMaxChannels
+            if ((b != 16 && b != 20 && b != 24 && b != 32) || J.info.channels < 1 || J.info.channels > 8) {  // kALACMaxChannels
                 fprintf(stderr, " File \"%s\'s\" data format is of an unsupported type\n", J.in.c_str());
                 return 1;
             }
@@ -310,10 +303,6 @@ int main(int argc, char *argv[])
                                                                       : alacfile::parse_alac_caf(J.file, J.info, c);
             if (!err.empty()) {
                 fprintf(stderr, " %s: \"%s\"\n", err.c_str(), J.in.c_str());
-                return 1;
-            }
-            if (source_bits(J.info.alacSourceFlag) == 20) {
-                fprintf(stderr, " 20-bit ALAC files are not supported by the convert utility: \"%s\"\n", J.in.c_str());
                 return 1;
             }
             key = "D" + std::string(c.cookie.begin(), c.cookie.end());

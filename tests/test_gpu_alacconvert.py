@@ -232,3 +232,52 @@ def test_multichannel_files(binary, oracle, tmp_path, bits, ch, frames):
     again = tmp_path / "again.caf"
     assert run(binary, back, again)[0] == 0
     assert again.read_bytes() == want
+
+
+@pytest.mark.parametrize("ch,frames", [(2, 4096 * 2 + 333), (1, 4096 + 40)])
+def test_20_bit_files(binary, oracle, tmp_path, ch, frames):
+    """20-bit material lives in 3-byte containers, left-justified (what the codec's mix20 / copy20ToPredictor read).  The
+    reference's utility sizes such a file with 20 >> 3 = 2 bytes per sample (convert-utility/main.cu:389) and so never handled
+    one; here the file is sized by its containers: the packets are the ones the codec oracle makes of the same PCM, in CAF and
+    in M4A, and both decode back to the input."""
+    import struct
+    from container_lib import Container
+    rng = np.random.default_rng(20 + ch)
+    t = np.arange(frames)
+    cols = [np.round((0.3 * np.sin(2 * np.pi * (300.0 + 90 * c) * t / 44100.0) + 0.02 * rng.standard_normal(frames)) * ((1 << 19) - 1))
+            for c in range(ch)]
+    v = np.stack(cols, axis=1).astype(np.int64)
+    pcm = ((v << 4) & 0xffffff).astype("<u4").view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+    bpf = ch * 3
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, ch, 48000, 48000 * bpf, bpf, 20) + b"data" + struct.pack("<I", len(pcm)) + pcm
+    wav = b"RIFF" + struct.pack("<I", len(body)) + body
+    src, caf, m4a = tmp_path / "in.wav", tmp_path / "out.caf", tmp_path / "out.m4a"
+    src.write_bytes(wav)
+    rc, _, err = run(binary, src, caf)
+    assert rc == 0, err
+    assert run(binary, src, m4a)[0] == 0
+    ct = Container()
+    cookie, sizes, dpos = ct.parse_alac_caf(caf.read_bytes())
+    enc = oracle.encoder(4096, 20, ch, 48000)
+    assert cookie == bytes(enc.cookie())
+    want = []
+    for p0 in range(0, frames, 4096):
+        n = min(4096, frames - p0)
+        want.append(bytes(enc.encode_packet(np.frombuffer(pcm[p0 * bpf:(p0 + n) * bpf], np.uint8), n)))
+    assert [int(s) for s in sizes] == [len(w) for w in want]
+    assert caf.read_bytes()[dpos:dpos + sum(len(w) for w in want)] == b"".join(want)
+    info, cookie2, sizes2, pos2 = ct.parse_alac_m4a(m4a.read_bytes())
+    assert cookie2 == cookie and list(sizes2) == list(sizes)
+    for packed in (caf, m4a):
+        back = tmp_path / (packed.name + ".wav")
+        rc, _, err = run(binary, packed, back)
+        assert rc == 0, err
+        b = back.read_bytes()
+        assert b[44:] == pcm
+        assert struct.unpack("<HHIIHH", b[20:36]) == (1, ch, 48000, 48000 * bpf, bpf, 20)
+    # PCM CAF out (3-byte samples, 20 valid bits) is a valid encode input again
+    back_caf, again = tmp_path / "back.caf", tmp_path / "again.caf"
+    assert run(binary, caf, back_caf)[0] == 0
+    assert back_caf.read_bytes().endswith(pcm)
+    assert run(binary, back_caf, again)[0] == 0
+    assert again.read_bytes() == caf.read_bytes()
