@@ -471,6 +471,46 @@ class CabiReassembler:
                     mode="C-ABI: ncclAllGather of the shard table + one ncclSend/ncclRecv group")
 
 
+class TorchReassembler:
+    """The same exchange on torch.distributed (alac_amd.reassemble.Reassembler) behind CabiReassembler's interface: only used
+    when the C-ABI communicator could not be created on EVERY rank (a collective decision, see make_reassembler) — the line
+    then says so in `reassembly_path`."""
+
+    def __init__(self, dist):
+        from alac_amd.reassemble import Reassembler
+        self.r = Reassembler(dist.group.WORLD)
+
+    def begin(self, b):
+        return self.r.begin(b["out"], b["offsets"][-1:], b["sizes"])
+
+    def finish(self, h, b):
+        g = self.r.finish(h)
+        offs = [int(x) for x in g["offsets"].tolist()]
+        return dict(stream=g["stream"], total=g["total"], offsets=offs, sizes=g["sizes"],
+                    lens=[offs[r + 1] - offs[r] for r in range(len(offs) - 1)],
+                    mode="torch.distributed fallback: " + g["mode"])
+
+
+def make_reassembler(torch, dist, alac_amd, device, rank, world, packets, shard_capacity):
+    """C-ABI communicator on every rank, or — if ANY rank could not create it — torch.distributed on every rank.  Creation is
+    itself collective (ncclCommInitRank), so a rank only gets to fail before it: a missing librccl, a refused argument; the
+    verdict is all-reduced so that no rank runs a different exchange from its peers."""
+    ra, err = None, ""
+    try:
+        if os.environ.get("ALAC_BENCH_NO_CABI_COMM"):  # rehearsal of the fallback (set on every rank or on one)
+            raise RuntimeError("ALAC_BENCH_NO_CABI_COMM is set")
+        ra = CabiReassembler(torch, dist, alac_amd, device, rank, world, packets, shard_capacity)
+    except Exception as e:  # noqa: BLE001 - reported in the line
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1 if ra is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return ra, "C-ABI (alac_hip_comm_* / alac_hip_reassemble_begin/_finish on librccl)"
+    print(f"bench.py rank {rank}: C-ABI communicator unavailable on some rank ({err or 'another rank'}); "
+          "re-assembly falls back to torch.distributed", file=sys.stderr)
+    return TorchReassembler(dist), "torch.distributed fallback (" + (err or "another rank failed") + ")"
+
+
 def alac_amd_slots():
     from alac_amd.capi import COMM_SLOTS
     return COMM_SLOTS
@@ -531,7 +571,8 @@ def rank_main_body(args, json_fd):
     nbuf = 3 if reassemble else 2
     bufs = [ctx.encode_buffers(fmt, B) for _ in range(nbuf)]
     comm_stream = torch.cuda.Stream() if reassemble else None
-    ra = CabiReassembler(torch, dist, alac_amd, local_rank, rank, world, B, bufs[0]["out"].numel()) if reassemble else None
+    ra, ra_path = (make_reassembler(torch, dist, alac_amd, local_rank, rank, world, B, bufs[0]["out"].numel()) if reassemble
+                   else (None, None))
     state = {"pending": None, "gather": None, "timing": False, "ev": [], "on": reassemble}
 
     def timed(fn):
@@ -708,6 +749,8 @@ def rank_main_body(args, json_fd):
             out["ms_per_encode_no_reassemble"] = round(dt_plain / n_pass * 1e3, 4)
             out["value_note"] = ("`value` includes the RCCL re-assembly of every pass (overlapped with the next pass's encode); "
                                  "`value_no_reassemble` is the same K steps with the exchange switched off, timed right after")
+        if ra_path is not None:
+            out["reassembly_path"] = ra_path
         if reasm_ms is not None:
             out["reassembly_ms"] = round(reasm_ms, 4)
             out["reassembly_note"] = ("device time per encode pass of the exchange (length all-gathers + grouped send/recv of the shard "
