@@ -417,3 +417,51 @@ def test_corrupt_packets_differential(gpu_ctx, oracle, block):
                 both0 += 1
                 assert ns[p] == m and np.array_equal(out[p * fmt.packet_bytes:p * fmt.packet_bytes + m * bpf], want), (seed, p)
     assert both0 > 300
+
+
+@pytest.mark.parametrize("depth", [16, 24])
+@pytest.mark.parametrize("separate", [False, True])
+def test_stream_at_any_byte_alignment(gpu_ctx, oracle, depth, separate):
+    """The caller's stream may start at any byte: the header window (LDS copy of a packet's first 64 bytes, dword loads), the
+    direct reads of the separate launches and the escape-element groups all assume a dword-aligned base and must fall back to
+    their byte / staged forms otherwise.  The same packets (compressed, escaped, partial, one within 68 bytes of the stream's
+    end) decode identically from a base shifted by 0..3 bytes, in the fused launch and in the separate launches."""
+    import torch
+    fmt = alac_amd.make_format(4096, depth, 2)
+    n = 96
+    rng = np.random.default_rng(77 + depth)
+    pcm = alac_amd.synth_pcm(5, n, fmt).copy()
+    noise = rng.integers(0, 256, fmt.packet_bytes, dtype=np.uint8)
+    for p in range(3, n, 7):  # full-scale noise: escape packets
+        pcm[p * fmt.packet_bytes:(p + 1) * fmt.packet_bytes] = noise
+    sizes = [4096] * n
+    sizes[10], sizes[11], sizes[n - 1] = 100, 4095, 4  # partial frames; a tiny last packet near the stream's end
+    enc = oracle.encoder(4096, depth, 2)
+    pkts = []
+    for p in range(n):
+        enc.reset()
+        pkts.append(enc.encode_packet(pcm[p * fmt.packet_bytes:p * fmt.packet_bytes + sizes[p] * fmt.bytes_per_frame], sizes[p]))
+    assert any(len(pkts[p]) > fmt.packet_bytes for p in range(3, n, 7))  # escapes really happened
+    stream = np.concatenate(pkts)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in pkts])]).astype(np.int64)
+    cookie = oracle.encoder(4096, depth, 2).cookie()
+    gpu_ctx.set_option("dec_fused", 0 if separate else 1)
+    try:
+        ref = None
+        for shift in range(4):
+            buf = torch.zeros(len(stream) + 8, dtype=torch.uint8, device="cuda")
+            buf[shift:shift + len(stream)] = torch.from_numpy(stream).cuda()
+            view = buf[shift:shift + len(stream)]
+            assert view.data_ptr() % 4 == shift
+            out, ns, st, _ = gpu_ctx.decode(cookie, view, torch.from_numpy(offs).cuda(), n)
+            gpu_ctx.synchronize()
+            assert st.cpu().tolist() == [0] * n and ns.cpu().tolist() == sizes, shift
+            out = out.cpu().numpy()
+            for p in range(n):
+                a, k = p * fmt.packet_bytes, sizes[p] * fmt.bytes_per_frame
+                assert np.array_equal(out[a:a + k], pcm[a:a + k]), (shift, p)
+            if ref is None:
+                ref = out
+            assert np.array_equal(out, ref), shift
+    finally:
+        gpu_ctx.set_option("dec_fused", -1)
