@@ -40,9 +40,23 @@ constexpr int kWinStride = 33;   // LDS words per lane: a circular ring of 32 (+
 
 // ---- k_dec_stage ---------------------------------------------------------------------------------
 // words[i] = bytes 4i .. 4i+3 of the stream as one MSB-first word, followed by 64 words of zeros
-__global__ __launch_bounds__(256) void k_dec_stage(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets,
-                                                   uint32_t *words, uint64_t capWords)
+// zeroA[0 .. nA) and zeroB[0]: the pass's device counters (work-list counters, mismatch count).  As hipMemsetAsync calls in front
+// of the first kernel they were two blit launches with a 30-50 us bubble in front of the first (rocprofv3 kernel trace of
+// back-to-back decode passes, round 4); the first kernel of the pass clears them instead.
+struct DecZero {
+    uint32_t *a, *b;
+    uint32_t nA;
+};
+__device__ __forceinline__ void dec_zero(const DecZero &z)
 {
+    if (blockIdx.x != 0) return;
+    if (z.a && threadIdx.x < z.nA) z.a[threadIdx.x] = 0;
+    if (z.b && threadIdx.x == 0) z.b[0] = 0;
+}
+__global__ __launch_bounds__(256) void k_dec_stage(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets,
+                                                   uint32_t *words, uint64_t capWords, DecZero zero)
+{
+    dec_zero(zero);
     const uint64_t total = offsets[numPackets];
     const uint64_t fullWords = total >> 2;
     const bool aligned = ((uintptr_t)stream & 3) == 0;
@@ -177,8 +191,10 @@ __device__ __forceinline__ const uint32_t *dec_window_t(const DecV1Args &V, uint
 }
 
 // k_dec_tail (DIRECT): the end of the stream as dwords in the caller's byte order, zero-filled behind the last byte
-__global__ __launch_bounds__(kDecTailWords) void k_dec_tail(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets, uint32_t *tail)
+__global__ __launch_bounds__(kDecTailWords) void k_dec_tail(const uint8_t *stream, const uint64_t *offsets, uint32_t numPackets, uint32_t *tail,
+                                                            DecZero zero)
 {
+    dec_zero(zero);
     const uint64_t total = offsets[numPackets];
     const uint64_t fw = total >> 2, ts = fw > 16 ? fw - 16 : 0;
     const uint64_t i = ts + threadIdx.x;
@@ -1957,12 +1973,22 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     // every sample a later kernel reads is then written by somebody (coded rows: residuals + run zeros; uncompressed rows:
     // k_dec_raw; absent elements of a > 2-channel round: k_dec_unmix reads nothing), and the fill is left out
     const bool zerosWritten = !fused0;
+    // (the runtime's fill: a kernel of this library in its place — 44 us for the 328 MB of 10 000 stereo packets, HBM write speed —
+    // measured 1.745 against 1.733 ms per pass: no bubble in front of a fill that IS the pass's first real work, unlike the 4-byte
+    // ones DecZero replaced)
     if (!zerosWritten) (void)hipMemsetAsync(V.plane, 0, planeBytes, sc);
     if (useSide) (void)hipMemsetAsync(V.prog, 0, (size_t)da.numPackets * 8, sc);
-    if (V.mismatch) (void)hipMemsetAsync(V.mismatch, 0, 4, st);
     V.lists = fused0 ? 0u : 1u;
     V.pairs = (!fused0 && V.d.optPair != 0) ? 1u : 0u;
-    if (V.lists) (void)hipMemsetAsync(dec_lists(V).cnt, 0, kDecCounters * 4, st);
+    // the pass's counters: cleared by its first kernel (k_dec_tail / k_dec_stage, see DecZero) where there is one
+    DecZero zero;
+    zero.a = V.lists ? dec_lists(V).cnt : nullptr;
+    zero.nA = kDecCounters;
+    zero.b = V.mismatch;
+    if (!stageFirst) {
+        if (zero.b) (void)hipMemsetAsync(zero.b, 0, 4, st);
+        if (zero.a) (void)hipMemsetAsync(zero.a, 0, kDecCounters * 4, st);
+    }
     // DIRECT: separate launches of a mono / stereo stream whose buffer is dword aligned (the fused launch keeps the staged copy:
     // there the entropy wave is the launch's serial chain and the 38 us copy is cheaper than a swap per word on that chain)
     // Measured at 125 000 packets (round 4, same box, A/B in one process): 16-bit 5.55 -> 5.39 ms; 24-bit 6.92 -> 7.06 ms — there
@@ -1974,10 +2000,11 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
         V.raw = (const uint32_t *)da.stream;
         V.tail = V.words;                // the first words of the (otherwise unused) staging area
         V.capWords = 1ull << 40;         // no staging area, no truncation: the word limit is the stream's own end + 64
-        hipLaunchKernelGGL(k_dec_tail, dim3(1), dim3(kDecTailWords), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words));
+        hipLaunchKernelGGL(k_dec_tail, dim3(1), dim3(kDecTailWords), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
+                           zero);
     } else if (stageFirst)
         hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
-                           V.capWords);
+                           V.capWords, zero);
     hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
     if (useSide) {
         (void)hipEventRecord(side->join, sc);
@@ -2078,7 +2105,7 @@ hipError_t launch_decode_v1_elements(const DecodeArgs &da, const McElement *el, 
                                      uint32_t *mismatch, hipStream_t st)
 {
     if (da.numPackets == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords);
+    hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, words, capWords, DecZero{nullptr, nullptr, 0});
     (void)hipMemsetAsync(elemBit, 0, (size_t)da.numPackets * 4, st);
     (void)hipMemsetAsync(mismatch, 0, 4, st);
     for (uint32_t r = 0; r < numElements; r++) {
