@@ -418,7 +418,7 @@ def encode_leg(torch, alac_amd, ctx, fmt, B, passes=6, warm=2, every=997, with_d
         for _ in range(warm):
             ctx.encode(fmt, d_pcm, B, bufs=bufs)
         ctx.synchronize()
-        ctx.profile_begin(passes)
+        ctx.profile_begin(min(passes, 3))
         t0 = time.perf_counter()
         for _ in range(passes):
             ctx.encode(fmt, d_pcm, B, bufs=bufs)
@@ -624,7 +624,9 @@ def rank_main_body(args, json_fd):
     torch.cuda.synchronize()
 
     n_pass = args.steps * R
-    ctx.profile_begin(min(n_pass, 64))  # stage events of the first 64 timed passes
+    # stage events (HIP events between the launches, on the library's stream) of the first 16 timed passes only: an event between
+    # two launches costs 5-12 us of idle GPU (rocprofv3 kernel trace: back-to-back launches have no gap without them)
+    ctx.profile_begin(min(n_pass, 16))
     state["timing"] = True
     t0 = time.perf_counter()
     with torch.cuda.stream(ctx.stream):
