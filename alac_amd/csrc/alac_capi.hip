@@ -76,7 +76,7 @@ const AlacOptionKey *alac_option_keys(uint32_t *count)
         {"fused", &AlacOptions::fused, 0, 1},          {"fold", &AlacOptions::fold, 0, 1},
         {"fast_mode", &AlacOptions::fastMode, 0, 1},   {"encoder_lane", &AlacOptions::laneEncoder, 0, 1},
         {"decoder_lane", &AlacOptions::laneDecoder, 0, 1}, {"dec_fused", &AlacOptions::decFused, -1, 1},
-        {"dec_pair", &AlacOptions::decPair, 0, 1},     {"dec_direct", &AlacOptions::decDirect, 0, 1},
+        {"dec_pair", &AlacOptions::decPair, 0, 1},     {"dec_direct", &AlacOptions::decDirect, 0, 2},
         {"stage_taps", &AlacOptions::stageTaps, 0, 1},
         {"debug_lose_handoff", &AlacOptions::loseHandoff, 0, 1}, {"debug_waves", &AlacOptions::debugWaves, 0, 1},
     };

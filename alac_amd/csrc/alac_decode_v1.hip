@@ -1141,6 +1141,7 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
 // chain's own tap count, so there are no dead taps, no cross-lane exchange and the weights are compile-time constants)
 // and a wave walks 64 chains.  k_dec_header has sorted the chains the fast path accepts by tap count into ONE list filled
 // from both ends (dec_lists), and the packets whose two chains both qualify into the pair list.
+constexpr uint32_t kDecDirectPackets = 80000;  // separate launches read the caller's stream directly from here on (decode_v1_pass)
 constexpr uint64_t kDecFusedChains = 65536;  // up to here (32 768 stereo packets) one fused launch, above it separate launches
 
 // one unpc step of a lane that holds all T taps: returns out[j]; updates a[], the window w[] and tp
@@ -1994,7 +1995,12 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     // Measured at 125 000 packets (round 4, same box, A/B in one process): 16-bit 5.55 -> 5.39 ms; 24-bit 6.92 -> 7.06 ms — there
     // half of the stream is shifted-off bytes, which the predictor pairs fetch word by word (a swap and a select per word on
     // THEIR chain), so 20- / 24- / 32-bit streams keep the staged copy.
-    const bool direct = stageFirst && !fused0 && V.elemBit == nullptr && ((uintptr_t)da.stream & 3) == 0 && V.d.optDirect != 0 &&
+    // ... and only from kDecDirectPackets on (option dec_direct = 1, the default; 2 = whenever legal): with the entropy launch at
+    // one wave per SIMD or less every instruction on the lanes' serial chain counts, and the swap per word costs more than the
+    // copy it saves — 34 000 / 48 000 / 64 000 / 90 000 packets, direct against staged, one box: 2.99 / 2.85, 3.27 / 3.18,
+    // 3.36 / 3.29, 4.25 / 4.30 ms (profiles/r04/decode_direct_sweep.log)
+    const bool directWanted = V.d.optDirect == 2 || (V.d.optDirect == 1 && da.numPackets >= kDecDirectPackets);
+    const bool direct = stageFirst && !fused0 && V.elemBit == nullptr && ((uintptr_t)da.stream & 3) == 0 && directWanted &&
                         da.bitDepth == 16;
     if (direct) {
         V.raw = (const uint32_t *)da.stream;

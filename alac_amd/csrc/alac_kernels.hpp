@@ -103,7 +103,8 @@ struct AlacOptions {
     int32_t laneDecoder = 0;   // "decoder_lane" ALAC_HIP_DECODER=lane first-generation decoder
     int32_t decFused = -1;     // "dec_fused"    ALAC_HIP_DEC_FUSED   decode: entropy wave + its predictor waves in one launch, -1 = by batch size
     int32_t decPair = 1;       // "dec_pair"     ALAC_HIP_DEC_PAIR    decode, separate launches, 16-bit stereo: the predictor lanes of a packet un-mix and write the PCM
-    int32_t decDirect = 1;     // "dec_direct"   ALAC_HIP_DEC_DIRECT  decode, separate launches: read the caller's stream directly (no staged copy)
+    int32_t decDirect = 1;     // "dec_direct"   ALAC_HIP_DEC_DIRECT  decode, separate launches: read the caller's stream directly (no staged
+                               // copy): 0 never, 1 from kDecDirectPackets on, 2 whenever legal
     int32_t stageTaps = 1;     // "stage_taps"   ALAC_HIP_STAGE_TAPS  stage-level pc_block: tap-parallel kernel for 5..30 taps
     int32_t loseHandoff = 0;   // "debug_lose_handoff" ALAC_HIP_DEBUG_LOSE_HANDOFF  TEST switch: producers never publish (results invalid by design)
     int32_t debugWaves = 0;    // "debug_waves"  wave placement / timing stamps of the fused final launch into the workspace (tools/wave_map.py)

@@ -81,8 +81,9 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  *   "dec_fused" (-1/0/1)   decode: entropy wave + its predictor waves in one launch; automatic up to 65 536 chains
  *   "dec_pair" (0/1)       decode, separate launches, 16- / 20- / 24-bit stereo: the two predictor lanes of a packet un-mix and
  *                          write the PCM
- *   "dec_direct" (0/1)     decode, separate launches, 16-bit: the kernels read the caller's stream (dword aligned) instead of a
- *                          staged copy
+ *   "dec_direct" (0/1/2)   decode, separate launches, 16-bit: the kernels read the caller's stream (dword aligned) instead of a
+ *                          staged copy: 0 never, 1 (default) from 80 000 packets on (below that the swap per word on the
+ *                          entropy lanes' chain costs more than the copy), 2 whenever the stream allows it
  *   "stage_taps" (0/1)     alac_hip_pc_block: tap-parallel kernel for 5..30 taps
  *   "debug_waves" (0/1)    diagnostics, see alac_hip_debug_waves_offset
  *   "debug_lose_handoff" (0/1)  TEST switch, the one key that invalidates results by design: producers of the in-launch

@@ -231,7 +231,7 @@ def test_stream_beyond_the_workspace_fails_cleanly(gpu_ctx, oracle):
     assert rc == 0
     gpu_ctx.synchronize()
     st = st.cpu().tolist()
-    if gpu_ctx.get_option("decoder_lane") or (gpu_ctx.get_option("dec_fused") == 0 and gpu_ctx.get_option("dec_direct")):
+    if gpu_ctx.get_option("decoder_lane") or (gpu_ctx.get_option("dec_fused") == 0 and gpu_ctx.get_option("dec_direct") == 2):
         # the first-generation decoder, and the separate launches of a 16-bit stream (dec_direct), read the packets where they
         # lie (no staged copy): everything decodes
         assert st == [0] * n
@@ -445,7 +445,11 @@ def test_stream_at_any_byte_alignment(gpu_ctx, oracle, depth, separate):
     stream = np.concatenate(pkts)
     offs = np.concatenate([[0], np.cumsum([len(x) for x in pkts])]).astype(np.int64)
     cookie = oracle.encoder(4096, depth, 2).cookie()
+    keep_fused = gpu_ctx.get_option("dec_fused")  # (a variant session pins these: put them back as they were)
     gpu_ctx.set_option("dec_fused", 0 if separate else 1)
+    keep_direct = gpu_ctx.get_option("dec_direct")
+    if separate and keep_direct == 1:
+        gpu_ctx.set_option("dec_direct", 2)  # the direct reads at this batch size (automatic: from 80 000 packets on)
     try:
         ref = None
         for shift in range(4):
@@ -464,4 +468,5 @@ def test_stream_at_any_byte_alignment(gpu_ctx, oracle, depth, separate):
                 ref = out
             assert np.array_equal(out, ref), shift
     finally:
-        gpu_ctx.set_option("dec_fused", -1)
+        gpu_ctx.set_option("dec_fused", keep_fused)
+        gpu_ctx.set_option("dec_direct", keep_direct)

@@ -8,7 +8,7 @@ import alac_amd
 pytestmark = pytest.mark.gpu
 
 KEYS = {"thru": (-1, 1), "narrow": (-1, 1), "split_coder": (0, 1), "overlap_pos": (0, 1), "fused": (0, 1), "fold": (0, 1),
-        "fast_mode": (0, 1), "encoder_lane": (0, 1), "decoder_lane": (0, 1), "dec_fused": (-1, 1), "dec_pair": (0, 1), "dec_direct": (0, 1),
+        "fast_mode": (0, 1), "encoder_lane": (0, 1), "decoder_lane": (0, 1), "dec_fused": (-1, 1), "dec_pair": (0, 1), "dec_direct": (0, 2),
         "stage_taps": (0, 1), "debug_lose_handoff": (0, 1), "debug_waves": (0, 1)}
 REMOVED = ["idlefast", "wide81", "pubfence", "subbatch", "persist", "class_fused", "search_fused", "thru_wg4", "lds_pad",
            "count_walk", "init_state", "dec_wide", "dec_local", "dec_pubmask"]  # measured and rejected variants, gone in round 4

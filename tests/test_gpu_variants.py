@@ -16,7 +16,7 @@ FILES = ["tests/test_gpu_encode.py", "tests/test_gpu_decode.py", "tests/test_gpu
 
 VARIANTS = {
     "first-generation": {"encoder_lane": 1, "decoder_lane": 1},
-    "stagewise": {"fused": 0, "dec_fused": 0},
+    "stagewise": {"fused": 0, "dec_fused": 0, "dec_direct": 2},  # direct reads at every batch size (automatic: from 80 000 packets)
     "two-lane-latency-regime": {"narrow": 0},
     "two-lane-latency-regime-unfolded": {"narrow": 0, "fold": 0},
     "throughput-regime": {"thru": 1},
