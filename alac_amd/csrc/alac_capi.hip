@@ -223,8 +223,9 @@ EncLayout enc_layout(const alac_hip_format *f, uint32_t numPackets, uint32_t num
     off = align_up(off + 256 + ((uint64_t)numSegments / 1024 + 2) * 8, 256);
     L.colChain = off;
     off = align_up(off + (uint64_t)L.colsPad * 4, 256);
-    // Tiny batches (<= 4096 chains: a chained file, a few hundred files side by side; the four-lanes-per-chain regime of
-    // alac_encode_v1.hip): the final coder of a chain is split over two waves, the second one writes here
+    // The smallest batches (<= 4096 chains: a chained file, a few hundred files side by side — the low end of the
+    // four-lanes-per-chain regime, v1_narrow_regime): the final coder of a chain is split over two waves, the second one
+    // writes here
     L.bitWordsB = L.bitsB = 0;
     if (lanes <= 4096) {
         L.bitWordsB = off;
@@ -478,7 +479,7 @@ const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt
     const uint64_t chains = (uint64_t)num_segments * ch;
     // the launcher's own predicates (launch_encode_v1 / launch_v1_typed): fuse = fused && !thru, narrow = narrow && fuse
     if (!ctx->opt.fused) return "stagewise";
-    const bool narrow = ctx->opt.narrow >= 0 ? ctx->opt.narrow != 0 : chains <= 4096;
+    const bool narrow = v1_narrow_regime(chains, ctx->opt);
     return narrow ? "tiny" : "latency";
 }
 

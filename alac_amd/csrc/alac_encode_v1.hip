@@ -40,6 +40,22 @@ bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOpt
     return (uint64_t)numSegments * (channels > 2 ? 2 : channels) > 65536;
 }
 
+// Four lanes per chain ("tiny") or two ("latency") below the throughput regime.  Every launch of these regimes is made of
+// single-wave workers that want a SIMD to themselves (1024 SIMDs): five per 64 chains with four lanes per chain, three with two.
+// The four-lane form has the shorter serial chain and wins while ITS workers fit (measured crossover 5 500-6 000 packets = 11 000-
+// 12 000 chains, 16- and 24-bit); then the two-lane form while its workers fit (21 845 chains: at 10 000 packets 938 workers);
+// behind that cliff — 10 500 -> 11 000 packets: 1.46 -> 2.26 ms, some SIMDs now carry two predictor waves — the four-lane form,
+// already past its own cliff and flat, is faster again until ~17 000 packets (11 000 / 12 000 / 14 000 / 16 000 / 18 000 packets,
+// four against two lanes: 1.81 / 2.26, 1.82 / 2.44, 2.23 / 2.49, 2.34 / 2.54, 2.64 / 2.61 ms; profiles/r04/encode_regime_sweep.log).
+// Until round 4 the rule was "four lanes up to 4096 chains".
+bool v1_narrow_regime(uint64_t chains, const AlacOptions &opt)
+{
+    if (opt.narrow >= 0) return opt.narrow != 0;
+    if (chains <= 11264) return true;
+    if (chains <= 21760) return false;  // 3 workers per 64 chains <= 1020
+    return chains <= 34816;
+}
+
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
                             const V1Buffers &vb, const V1Streams &vs, uint32_t numPackets, uint32_t maxSegPackets,
                             hipStream_t st, hipEvent_t *ev)
@@ -73,8 +89,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         const uint64_t chains = (uint64_t)ea.numSegments * channels;
         A.thru = v1_throughput_regime(ea.numSegments, channels, vb.opt) ? 1u : 0u;
         A.idleFast = A.thru ? 0u : 1u;
-        const int forcedNarrow = vb.opt.narrow;
-        A.narrow = forcedNarrow >= 0 ? (uint32_t)forcedNarrow : (chains <= 4096 ? 1u : 0u);
+        A.narrow = v1_narrow_regime(chains, vb.opt) ? 1u : 0u;
     }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;

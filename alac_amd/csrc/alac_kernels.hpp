@@ -93,7 +93,7 @@ struct HandoffCtl {
 // from the batch shape).
 struct AlacOptions {
     int32_t thru = -1;         // "thru"         ALAC_HIP_THRU        encode: throughput (1) / latency (0) regime, -1 = by batch size
-    int32_t narrow = -1;       // "narrow"       ALAC_HIP_NARROW      tiny batches: four lanes per chain, -1 = by batch size
+    int32_t narrow = -1;       // "narrow"       ALAC_HIP_NARROW      four lanes per chain, -1 = by batch size (v1_narrow_regime)
     int32_t splitCoder = 1;    // "split_coder"  ALAC_HIP_SPLIT_CODER tiny batches: final coder of a chain on two waves
     int32_t overlapPos = 1;    // "overlap_pos"  ALAC_HIP_OVERLAP_POS chained batches: position p + 1's search beside p's final pass
     int32_t fused = 1;         // "fused"        ALAC_HIP_FUSED       producer/consumer launches (latency regime); 0 = one kernel per stage
@@ -150,6 +150,7 @@ void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint3
                            uint32_t *segBad,
                            hipStream_t st);
 bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt);
+bool v1_narrow_regime(uint64_t chains, const AlacOptions &opt);  // four lanes per chain ("tiny") rather than two ("latency")
 // ev (nullable): kEventBlocks blocks of kNumStages + 1 events
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
                             const V1Buffers &vb, const V1Streams &vs, uint32_t numPackets, uint32_t maxSegPackets,

@@ -69,7 +69,8 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  * defaults a context is created with.  Keys (value range; -1 = automatic):
  *   "thru" (-1/0/1)        encode: throughput regime — one kernel per stage, a chain's predictor and coder in one lane,
  *                          final pass per packet class; automatic above 65 536 chains
- *   "narrow" (-1/0/1)      encode: four lanes per chain (tiny batches, chained files); automatic up to 4096 chains
+ *   "narrow" (-1/0/1)      encode: four lanes per chain instead of two; automatic (-1): up to 11 264 chains (5 632 stereo packets),
+ *                          and again from 21 761 to 34 816 chains, where the two-lane workers no longer have a SIMD each
  *   "fused" (0/1)          encode: predictor || entropy coder as producer/consumer launches (latency and tiny regimes);
  *                          0 = one plain kernel per stage ("stagewise": also what frames above 524 287 samples get)
  *   "fold" (0/1)           latency regime: numU / numV / escape decision and the packet sizes inside the final launch

@@ -238,3 +238,31 @@ def test_tiny_frames_ending_in_zero_runs(gpu_ctx, oracle, opts):
         ref, ref_sizes = _oracle_stream(oracle, fmt, pcm, n * frame, 1)
         assert np.array_equal(sizes, ref_sizes), (frame, np.nonzero(sizes != ref_sizes)[0][:8])
         assert np.array_equal(stream, ref), frame
+
+
+@pytest.mark.parametrize("depth,n,regime", [(16, 5632, "tiny"), (16, 5700, "latency"), (16, 10880, "latency"), (16, 11000, "tiny"),
+                                            (24, 12000, "tiny"), (16, 17408, "tiny"), (16, 17500, "latency")])
+def test_regime_windows_below_the_throughput_regime(gpu_ctx, oracle, depth, n, regime):
+    """The automatic choice between four and two lanes per chain (v1_narrow_regime): four lanes up to 11 264 chains, two while
+    their workers have a SIMD each (21 760 chains), four again up to 34 816 chains, two from there to the throughput regime.
+    At both edges of every window: the regime the library reports, packets equal to the oracle's on a sample that covers all
+    eight signal classes, and the whole batch decodes back to the input."""
+    import torch
+    fmt = alac_amd.make_format(4096, depth, 2)
+    if gpu_ctx.get_option("narrow") == -1 and gpu_ctx.get_option("thru") == -1 and gpu_ctx.get_option("fused") != 0 \
+            and not gpu_ctx.get_option("encoder_lane"):
+        assert gpu_ctx.regime(fmt, n) == regime
+    d_pcm = gpu_ctx.synth_pcm(7, n, fmt)
+    b = gpu_ctx.encode(fmt, d_pcm, n)
+    gpu_ctx.synchronize()
+    offs = b["offsets"].cpu().numpy()
+    idx = sorted(set(list(range(0, n, 397)) + [0, 1, 63, 64, n - 65, n - 64, n - 1]))
+    assert {(7 + p) % 8 for p in idx} == set(range(8))
+    enc = oracle.encoder(4096, depth, 2)
+    for p in idx:
+        enc.reset()
+        want = enc.encode_packet(alac_amd.synth_pcm(7 + p, 1, fmt), 4096)
+        assert np.array_equal(b["out"][int(offs[p]):int(offs[p + 1])].cpu().numpy(), want), p
+    out, ns, st, _ = gpu_ctx.decode(gpu_ctx.magic_cookie(fmt), b["out"], b["offsets"], n, zero_fill=False)
+    gpu_ctx.synchronize()
+    assert int(st.abs().sum()) == 0 and torch.equal(out, d_pcm)
