@@ -47,6 +47,17 @@ def test_ragged_segment_count(gpu_ctx, oracle, depth, channels):
            [0, 1, 2, 7, 8, 15, 16, 17, 31, 32, 63, 64, nseg // 2, nseg - 18, nseg - 17, nseg - 16, nseg - 2, nseg - 1])
 
 
+@pytest.mark.parametrize("depth,channels,nseg", [(16, 2, 3000), (16, 2, 5632), (24, 2, 11500), (16, 1, 9000)])
+def test_chained_segments_in_the_wider_four_lane_windows(gpu_ctx, oracle, depth, channels, nseg):
+    """Round 4 widened the four-lanes-per-chain regime (up to 11 264 chains, and 21 761..34 816): chained segments at those
+    counts now run with overlapped packet positions and WITHOUT the split final coder (its buffers stop at 4096 chains) — a
+    combination the shapes above never reach.  3 packets per segment, 1024-sample frames, sampled segments against the oracle's
+    chains, at a count inside the first window, at its edge, inside the second window, and a mono batch."""
+    per = 3
+    _check(gpu_ctx, oracle, alac_amd.make_format(1024, depth, channels), nseg, per,
+           [0, 1, 2, 15, 16, 31, 32, 63, 64, 65, nseg // 3, nseg // 2, nseg - 65, nseg - 64, nseg - 17, nseg - 2, nseg - 1])
+
+
 def test_segment_bound_instead_of_read_back(gpu_ctx, oracle):
     """alac_hip_encode_segmented: with the caller's bound on the segment length nothing is read back; an over-estimate gives the
     same bytes, a table that contradicts the bound fails the next synchronize (kALAC_ParamError) instead of encoding garbage"""
