@@ -244,11 +244,12 @@ enum : uint32_t { kStIdle = 0, kStGolomb = 1, kStRaw = 2 };
 
 // ---- k_dec_header: element / header parse, once per packet, with the plain byte reader
 // (codec/ALACDecoder.cu:600-700).  Leaves the record, the payload position and the status behind.
-__global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
+constexpr int kHdrWaves = 4;  // waves per workgroup of k_dec_header (the work-list counters are bumped once per workgroup)
+__global__ __launch_bounds__(64 * kHdrWaves) void k_dec_header(DecV1Args V)
 {
     const DecodeArgs &A = V.d;
-    const int lane = threadIdx.x;
-    const uint32_t p = blockIdx.x * 64u + lane;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t p = blockIdx.x * (64u * kHdrWaves) + tid;
     const bool live = p < A.numPackets;
     const uint64_t off = live ? A.offsets[p] : 0;
     const uint64_t nbytes = live ? A.offsets[p + 1] - off : 0;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     // LDS words and a funnel shift instead of five byte loads, each a round trip of its own for 64 lanes in 64 different lines
     // (the launch took 0.114 ms of the 5.1 ms decode pass at 125 000 packets for 3 M wave-instructions).  Fields outside the
     // window, packets within 80 bytes of the stream's end and streams that are not dword aligned use the byte reader.
-    __shared__ uint32_t win[64 * kHdrWinStride];
+    __shared__ uint32_t win[64 * kHdrWaves * kHdrWinStride];
     const uint64_t totalBytes = A.offsets[A.numPackets];
     const bool useWin = live && ((uintptr_t)A.stream & 3) == 0 && (off & ~3ull) + 4 * kHdrWinWords <= totalBytes;
     const uint32_t phase = (uint32_t)(off & 3) * 8;  // bit of the packet's first byte inside window word 0
@@ -274,14 +275,14 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
             const int64_t keep = endRel - 4 * i;  // bytes of this word that belong to the packet
             if (keep <= 0) w = 0;
             else if (keep < 4) w &= 0xffffffffu << (8 * (4 - (int)keep));
-            win[lane * kHdrWinStride + i] = w;
+            win[tid * kHdrWinStride + i] = w;
         }
     }
     auto rd = [&](uint32_t n) -> uint32_t {
         const uint64_t bit = hpos + phase;
         if (useWin && bit + 32 <= 32ull * (kHdrWinWords - 1)) {
             const uint32_t wi = (uint32_t)(bit >> 5), sh = (uint32_t)(bit & 31);
-            const uint64_t two = ((uint64_t)win[lane * kHdrWinStride + wi] << 32) | win[lane * kHdrWinStride + wi + 1];
+            const uint64_t two = ((uint64_t)win[tid * kHdrWinStride + wi] << 32) | win[tid * kHdrWinStride + wi + 1];
             hpos += n;
             return n ? (uint32_t)((two << sh) >> 32) >> (32 - n) : 0u;
         }
@@ -439,27 +440,58 @@ __global__ __launch_bounds__(64) void k_dec_header(DecV1Args V)
     const bool rawDirect = rawP && stereo16 && R.elementChannels == 2;
     if (live) rec->pad2 = (pair || rawDirect) ? 1u : 0u;
     if (V.lists) {
+        // Every entry of a list costs its wave a fetch-and-add on the list's counter, and 125 000 packets are 1 954 waves bumping
+        // the same three or four words: ~50 of the launch's 90 us were that queue at the L2.  The waves of a workgroup first
+        // add up in LDS, one lane per counter then bumps the global word once for the whole workgroup (a quarter of the
+        // atomics, issued side by side instead of one round trip after the other), and the entries are written behind a barrier.
         const DecLists L = dec_lists(V);
         const uint64_t below = (1ull << lane) - 1;
-        auto push = [&](bool mine, uint32_t counter, uint32_t *list, uint32_t value, bool fromBack, uint32_t size) {
+        __shared__ uint32_t blkCnt[8], blkBase[8];
+        if (tid < 8) blkCnt[tid] = 0;
+        __syncthreads();
+        constexpr int kPushes = 10;
+        uint32_t slot[kPushes];  // this lane's index inside its workgroup's share of the counter, or ~0u
+        int np = 0;
+        auto count = [&](bool mine, uint32_t counter) {
             const uint64_t m = __ballot(mine);
             uint32_t b = 0;
-            if (lane == 0 && m) b = atomicAdd(L.cnt + counter, (uint32_t)__popcll(m));
+            if (lane == 0 && m) b = atomicAdd(&blkCnt[counter], (uint32_t)__popcll(m));  // LDS
             b = (uint32_t)__shfl((int)b, 0) + (uint32_t)__popcll(m & below);
-            if (mine) list[fromBack ? size - 1 - b : b] = value;
+            slot[np++] = mine ? b : ~0u;
         };
         const uint32_t total = A.numPackets * A.numChannels;
         const bool wide0 = widec[0], wide1 = widec[1];
-        push(ok0 && !pair && !wide0, 0, L.chains, p * A.numChannels, false, total);
-        push(ok0 && !pair && wide0, 1, L.chains, p * A.numChannels, true, total);
-        push(ok1 && !pair && !wide1, 0, L.chains, p * A.numChannels + 1, false, total);
-        push(ok1 && !pair && wide1, 1, L.chains, p * A.numChannels + 1, true, total);
-        push(pair && !wide0 && !wide1, 2, L.pairs, p, false, A.numPackets);
-        push(pair && (wide0 || wide1), 3, L.pairs, p, true, A.numPackets);
-        push(good && fastShape && anyc[0], 6, L.any, p * A.numChannels, false, total);
-        push(good && fastShape && R.elementChannels == 2 && anyc[1], 6, L.any, p * A.numChannels + 1, false, total);
-        push(rawP, 4, L.raw, p, false, A.numPackets);
-        push(good && !pair && !rawDirect, 5, L.rest, p, false, A.numPackets);
+        count(ok0 && !pair && !wide0, 0);
+        count(ok0 && !pair && wide0, 1);
+        count(ok1 && !pair && !wide1, 0);
+        count(ok1 && !pair && wide1, 1);
+        count(pair && !wide0 && !wide1, 2);
+        count(pair && (wide0 || wide1), 3);
+        count(good && fastShape && anyc[0], 6);
+        count(good && fastShape && R.elementChannels == 2 && anyc[1], 6);
+        count(rawP, 4);
+        count(good && !pair && !rawDirect, 5);
+        __syncthreads();
+        if (tid < 8 && blkCnt[tid]) blkBase[tid] = atomicAdd(L.cnt + tid, blkCnt[tid]);
+        __syncthreads();
+        np = 0;
+        auto place = [&](uint32_t counter, uint32_t *list, uint32_t value, bool fromBack, uint32_t size) {
+            const uint32_t b = slot[np++];
+            if (b != ~0u) {
+                const uint32_t at = blkBase[counter] + b;
+                list[fromBack ? size - 1 - at : at] = value;
+            }
+        };
+        place(0, L.chains, p * A.numChannels, false, total);
+        place(1, L.chains, p * A.numChannels, true, total);
+        place(0, L.chains, p * A.numChannels + 1, false, total);
+        place(1, L.chains, p * A.numChannels + 1, true, total);
+        place(2, L.pairs, p, false, A.numPackets);
+        place(3, L.pairs, p, true, A.numPackets);
+        place(6, L.any, p * A.numChannels, false, total);
+        place(6, L.any, p * A.numChannels + 1, false, total);
+        place(4, L.raw, p, false, A.numPackets);
+        place(5, L.rest, p, false, A.numPackets);
     }
     (void)pbU;
     (void)pbV;
@@ -2011,7 +2043,7 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     } else if (stageFirst)
         hipLaunchKernelGGL(k_dec_stage, dim3(2048), dim3(256), 0, st, da.stream, da.offsets, da.numPackets, const_cast<uint32_t *>(V.words),
                            V.capWords, zero);
-    hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 63) / 64), dim3(64), 0, st, V);
+    hipLaunchKernelGGL(k_dec_header, dim3((da.numPackets + 64 * kHdrWaves - 1) / (64 * kHdrWaves)), dim3(64 * kHdrWaves), 0, st, V);
     if (useSide) {
         (void)hipEventRecord(side->join, sc);
         (void)hipStreamWaitEvent(st, side->join, 0);
