@@ -381,7 +381,17 @@ __global__ __launch_bounds__(1024) void k_scan_sizes(const uint32_t *sizes, uint
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t base = blockIdx.x * 1024u;
     uint64_t before = 0;
-    for (uint32_t i = tid; i < base; i += 1024) before += refused ? 0u : sizes[i];
+    {
+        // four sizes per load, four loads in flight: the last block of 125 000 packets re-adds 122 K elements, 30 iterations per
+        // thread instead of 122 dependent-latency-bound ones (38 -> ~12 us; base is a multiple of 1024)
+        typedef uint32_t U4 __attribute__((ext_vector_type(4), aligned(4)));
+        const U4 *s4 = (const U4 *)sizes;
+#pragma unroll 4
+        for (uint32_t i = tid; i < base / 4; i += 1024) {
+            const U4 q = s4[i];
+            before += refused ? 0ull : (uint64_t)q.x + q.y + q.z + q.w;
+        }
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
     const uint32_t i = base + tid;
