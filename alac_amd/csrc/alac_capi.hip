@@ -479,7 +479,7 @@ const char *alac_hip_encode_regime(alac_hip_ctx *ctx, const alac_hip_format *fmt
     const uint64_t chains = (uint64_t)num_segments * ch;
     // the launcher's own predicates (launch_encode_v1 / launch_v1_typed): fuse = fused && !thru, narrow = narrow && fuse
     if (!ctx->opt.fused) return "stagewise";
-    const bool narrow = v1_narrow_regime(chains, ctx->opt);
+    const bool narrow = v1_narrow_regime(chains, ch, ctx->opt);
     return narrow ? "tiny" : "latency";
 }
 

@@ -1174,7 +1174,15 @@ __device__ __forceinline__ void unpc_fast_body(const DecV1Args &V, uint32_t bloc
 // and a wave walks 64 chains.  k_dec_header has sorted the chains the fast path accepts by tap count into ONE list filled
 // from both ends (dec_lists), and the packets whose two chains both qualify into the pair list.
 constexpr uint32_t kDecDirectPackets = 80000;  // separate launches read the caller's stream directly from here on (decode_v1_pass)
-constexpr uint64_t kDecFusedChains = 65536;  // up to here (32 768 stereo packets) one fused launch, above it separate launches
+// One fused launch up to here, separate launches above: 32 768 stereo packets (30 000: 2.78 against 2.97 ms, 34 000: 3.28 against
+// 3.33 at 24 bits) — but a mono packet is half the entropy work behind the same workgroup count, and mono streams cross over
+// where the fused workgroups (one per 48 packets) reach four per CU: 45 000 packets 1.98 against 2.00 ms, 50 000 2.30 against
+// 2.07 (profiles/r04/decode_direct_sweep.log).  Until the end of round 4 mono used the stereo rule (65 536 chains).
+constexpr uint64_t kDecFusedChains = 65536, kDecFusedChainsMono = 49152;
+__host__ inline bool dec_fused_auto(uint32_t numPackets, uint32_t numChannels)
+{
+    return (uint64_t)numPackets * numChannels <= (numChannels == 1 ? kDecFusedChainsMono : kDecFusedChains);
+}
 
 // one unpc step of a lane that holds all T taps: returns out[j]; updates a[], the window w[] and tp
 template <int T>
@@ -1993,7 +2001,7 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     const DecodeArgs &da = V.d;
     const uint64_t planeBytes = (uint64_t)da.numPackets * da.numChannels * da.frameSize * 4;
     const int forced0 = V.d.optFused;
-    const bool fused0 = forced0 >= 0 ? forced0 != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
+    const bool fused0 = forced0 >= 0 ? forced0 != 0 : dec_fused_auto(da.numPackets, da.numChannels);
     const bool useSide = side && side->stream && fused0;
     hipStream_t sc = useSide ? side->stream : st;  // the clears
     if (useSide) {
@@ -2056,7 +2064,7 @@ static hipError_t decode_v1_pass(const DecV1Args &V0, hipStream_t st, const DecS
     // profiles/r03/regime_sweep.log): 10 000 1.72 / 2.9 ms, 22 000 2.19 / 2.78, 26 000 2.58 / 2.86, 30 000 2.78 / 2.85,
     // 34 000 2.84 / 2.88, 125 000 17.6 (round 1) / 5.3.  Option dec_fused (ALAC_HIP_DEC_FUSED) = 0 / 1 forces.
     const int forced = V.d.optFused;
-    const bool fused = forced >= 0 ? forced != 0 : (uint64_t)da.numPackets * da.numChannels <= kDecFusedChains;
+    const bool fused = forced >= 0 ? forced != 0 : dec_fused_auto(da.numPackets, da.numChannels);
     if (fused) {
         const uint32_t nEntWg = (da.numPackets + kFusedPpw - 1) / kFusedPpw;
         hipLaunchKernelGGL(k_dec_fused_wg, dim3(nEntWg + (da.numPackets + 3) / 4), dim3(256), 0, st, V, nEntWg);

@@ -47,13 +47,16 @@ bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOpt
 // behind that cliff — 10 500 -> 11 000 packets: 1.46 -> 2.26 ms, some SIMDs now carry two predictor waves — the four-lane form,
 // already past its own cliff and flat, is faster again until ~17 000 packets (11 000 / 12 000 / 14 000 / 16 000 / 18 000 packets,
 // four against two lanes: 1.81 / 2.26, 1.82 / 2.44, 2.23 / 2.49, 2.34 / 2.54, 2.64 / 2.61 ms; profiles/r04/encode_regime_sweep.log).
-// Until round 4 the rule was "four lanes up to 4096 chains".
-bool v1_narrow_regime(uint64_t chains, const AlacOptions &opt)
+// Until round 4 the rule was "four lanes up to 4096 chains".  Mono streams (no mixRes search, whose five passes are where the
+// four-lane form gains most) cross over earlier at both ends: 10 000 / 11 000 chains 0.93 / 0.99 against 1.07 / 1.00 ms, and
+// 26 000 / 28 000 chains 1.55 / 1.77 against 1.97 / 1.78 — there the four-lane workers reach two per SIMD (26 214 chains).
+bool v1_narrow_regime(uint64_t chains, uint32_t channels, const AlacOptions &opt)
 {
     if (opt.narrow >= 0) return opt.narrow != 0;
-    if (chains <= 11264) return true;
+    const bool mono = channels == 1;
+    if (chains <= (mono ? 10240u : 11264u)) return true;
     if (chains <= 21760) return false;  // 3 workers per 64 chains <= 1020
-    return chains <= 34816;
+    return chains <= (mono ? 26112u : 34816u);
 }
 
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
@@ -89,7 +92,7 @@ hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs 
         const uint64_t chains = (uint64_t)ea.numSegments * channels;
         A.thru = v1_throughput_regime(ea.numSegments, channels, vb.opt) ? 1u : 0u;
         A.idleFast = A.thru ? 0u : 1u;
-        A.narrow = v1_narrow_regime(chains, vb.opt) ? 1u : 0u;
+        A.narrow = v1_narrow_regime(chains, channels, vb.opt) ? 1u : 0u;
     }
     A.packetBytes = ea.packetBytes;
     A.flags = vb.flags;

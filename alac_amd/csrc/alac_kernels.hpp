@@ -150,7 +150,7 @@ void launch_check_segments(const uint32_t *segFirst, uint32_t numSegments, uint3
                            uint32_t *segBad,
                            hipStream_t st);
 bool v1_throughput_regime(uint32_t numSegments, uint32_t channels, const AlacOptions &opt);
-bool v1_narrow_regime(uint64_t chains, const AlacOptions &opt);  // four lanes per chain ("tiny") rather than two ("latency")
+bool v1_narrow_regime(uint64_t chains, uint32_t channels, const AlacOptions &opt);  // four lanes per chain ("tiny") rather than two ("latency")
 // ev (nullable): kEventBlocks blocks of kNumStages + 1 events
 hipError_t launch_encode_v1(uint32_t depth, uint32_t channels, const EncodeArgs &ea, const PackArgs &pa,
                             const V1Buffers &vb, const V1Streams &vs, uint32_t numPackets, uint32_t maxSegPackets,

@@ -69,8 +69,9 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  * defaults a context is created with.  Keys (value range; -1 = automatic):
  *   "thru" (-1/0/1)        encode: throughput regime — one kernel per stage, a chain's predictor and coder in one lane,
  *                          final pass per packet class; automatic above 65 536 chains
- *   "narrow" (-1/0/1)      encode: four lanes per chain instead of two; automatic (-1): up to 11 264 chains (5 632 stereo packets),
- *                          and again from 21 761 to 34 816 chains, where the two-lane workers no longer have a SIMD each
+ *   "narrow" (-1/0/1)      encode: four lanes per chain instead of two; automatic (-1): up to 11 264 chains (5 632 stereo packets;
+ *                          mono: 10 240), and again from 21 761 to 34 816 chains (mono: 26 112), where the two-lane workers no
+ *                          longer have a SIMD each
  *   "fused" (0/1)          encode: predictor || entropy coder as producer/consumer launches (latency and tiny regimes);
  *                          0 = one plain kernel per stage ("stagewise": also what frames above 524 287 samples get)
  *   "fold" (0/1)           latency regime: numU / numV / escape decision and the packet sizes inside the final launch
@@ -79,7 +80,7 @@ int32_t alac_hip_synchronize(alac_hip_ctx *ctx);
  *   "fast_mode" (0/1)      ALACEncoder::SetFastMode: the search-free stereo path (EncodeStereoFast)
  *   "encoder_lane", "decoder_lane" (0/1)   the first-generation lane-per-chain kernels (a second, structurally different
  *                          implementation kept for differential testing)
- *   "dec_fused" (-1/0/1)   decode: entropy wave + its predictor waves in one launch; automatic up to 65 536 chains
+ *   "dec_fused" (-1/0/1)   decode: entropy wave + its predictor waves in one launch; automatic up to 65 536 chains (mono: 49 152)
  *   "dec_pair" (0/1)       decode, separate launches, 16- / 20- / 24-bit stereo: the two predictor lanes of a packet un-mix and
  *                          write the PCM
  *   "dec_direct" (0/1/2)   decode, separate launches, 16-bit: the kernels read the caller's stream (dword aligned) instead of a

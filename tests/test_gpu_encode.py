@@ -240,15 +240,17 @@ def test_tiny_frames_ending_in_zero_runs(gpu_ctx, oracle, opts):
         assert np.array_equal(stream, ref), frame
 
 
-@pytest.mark.parametrize("depth,n,regime", [(16, 5632, "tiny"), (16, 5700, "latency"), (16, 10880, "latency"), (16, 11000, "tiny"),
-                                            (24, 12000, "tiny"), (16, 17408, "tiny"), (16, 17500, "latency")])
-def test_regime_windows_below_the_throughput_regime(gpu_ctx, oracle, depth, n, regime):
+@pytest.mark.parametrize("depth,channels,n,regime", [(16, 2, 5632, "tiny"), (16, 2, 5700, "latency"), (16, 2, 10880, "latency"),
+                                                     (16, 2, 11000, "tiny"), (24, 2, 12000, "tiny"), (16, 2, 17408, "tiny"),
+                                                     (16, 2, 17500, "latency"), (16, 1, 10240, "tiny"), (16, 1, 10300, "latency"),
+                                                     (16, 1, 21800, "tiny"), (24, 1, 26112, "tiny"), (16, 1, 26200, "latency")])
+def test_regime_windows_below_the_throughput_regime(gpu_ctx, oracle, depth, channels, n, regime):
     """The automatic choice between four and two lanes per chain (v1_narrow_regime): four lanes up to 11 264 chains, two while
     their workers have a SIMD each (21 760 chains), four again up to 34 816 chains, two from there to the throughput regime.
     At both edges of every window: the regime the library reports, packets equal to the oracle's on a sample that covers all
     eight signal classes, and the whole batch decodes back to the input."""
     import torch
-    fmt = alac_amd.make_format(4096, depth, 2)
+    fmt = alac_amd.make_format(4096, depth, channels)
     if gpu_ctx.get_option("narrow") == -1 and gpu_ctx.get_option("thru") == -1 and gpu_ctx.get_option("fused") != 0 \
             and not gpu_ctx.get_option("encoder_lane"):
         assert gpu_ctx.regime(fmt, n) == regime
@@ -258,7 +260,7 @@ def test_regime_windows_below_the_throughput_regime(gpu_ctx, oracle, depth, n, r
     offs = b["offsets"].cpu().numpy()
     idx = sorted(set(list(range(0, n, 397)) + [0, 1, 63, 64, n - 65, n - 64, n - 1]))
     assert {(7 + p) % 8 for p in idx} == set(range(8))
-    enc = oracle.encoder(4096, depth, 2)
+    enc = oracle.encoder(4096, depth, channels)
     for p in idx:
         enc.reset()
         want = enc.encode_packet(alac_amd.synth_pcm(7 + p, 1, fmt), 4096)

@@ -30,9 +30,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--passes", type=int, default=10)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--state", action="store_true", help="pass a caller-owned coefficient state (k_init_state runs)")
     a = ap.parse_args()
-    fmt = alac_amd.make_format(4096, a.depth, 2, 44100)
+    fmt = alac_amd.make_format(4096, a.depth, a.channels, 44100)
     B = a.packets
     ctx = alac_amd.Context(0)
     d_pcm = ctx.synth_pcm(0, B, fmt)
